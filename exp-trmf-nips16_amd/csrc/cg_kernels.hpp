@@ -1,0 +1,327 @@
+// cg_kernels.hpp -- the X-solve (temporal factor) on device: TRON reduced to one truncated CG pass
+// (rf_tron.h:134-254, 412-505 with the fold of trmf.cpp:603-606), the AR + ridge operator
+// (trmf.cpp:70-149) and the cached-Gram Hessian product (replaces trmf.cpp:269-288).
+//
+// Control flow lives on the device.  Every scalar of the CG (alpha, beta, r^T r, the stop test,
+// the accept decision) is re-derived inside each kernel from fixed-order per-block partial sums
+// written by the previous kernel, so
+//   * the host enqueues the whole solve without a single synchronisation,
+//   * every workgroup -- and, with several GPUs, every rank -- derives bit-identical scalars,
+//   * a stop is "sticky": once ||r|| <= cgtol, cg_update_kernel only forwards the partials, so all
+//     later (already enqueued) iterations see the same r^T r and do nothing.
+//
+// Vectors are T x KP row-major (KP = padded rank); pad columns are zero and stay zero.
+#pragma once
+
+#include "common.hpp"
+
+namespace trmf {
+
+struct XState {
+    double f, fnew, gnorm, cg_rnorm, actred, prered, gs, sr;
+    double loss0, loss1;          // sum of squared residuals at w and at w_new (reduce_rows_kernel)
+    real cgtol;
+    int cg_iter, accepted;
+};
+
+// partial-sum arrays: Pbase[slot * kMaxPartials + block]
+enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_NSLOTS = 7 };
+
+struct XParams {
+    int T, k, KP, nlag, midx;
+    double lambdaI, lambdaAR, eps_cg;
+};
+
+// Fixed-order block reduction (blockDim.x == 256). Result valid in every thread.
+__device__ __forceinline__ double block_allsum(double v, double *smem /* >= 256 */) {
+    smem[threadIdx.x] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) smem[threadIdx.x] += smem[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double r = smem[0];
+    __syncthreads();
+    return r;
+}
+// Sum of a partial array written by a producer kernel with `np` blocks; identical in every block.
+__device__ __forceinline__ double sum_partials(const double *__restrict__ P, int np, double *smem) {
+    double v = 0;
+    for (int i = threadIdx.x; i < np; i += 256) v += P[i];
+    return block_allsum(v, smem);
+}
+__device__ __forceinline__ bool cg_stopped(real rho, real cgtol) {           // rf_tron.h:444-446
+    return sqrt((double)rho) <= (double)cgtol;
+}
+
+// ---- single-block reduction of a per-row array into a scalar ----------------------------------------
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ src, int n,
+                                                          double *__restrict__ dst) {
+    __shared__ double smem[256];
+    double v = 0;
+    for (int i = threadIdx.x; i < n; i += 256) v += src[i];
+    v = block_allsum(v, smem);
+    if (threadIdx.x == 0) *dst = v;
+}
+
+// ---- ||v||_F^2 partials (verbose log lines trmf.cpp:661,672,687) -----------------------------------
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const real *__restrict__ v, size_t n,
+                                                            double *__restrict__ P) {
+    __shared__ double smem[256];
+    double acc = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        acc += (double)v[i] * (double)v[i];
+    acc = block_allsum(acc, smem);
+    if (threadIdx.x == 0) P[blockIdx.x] = acc;
+}
+
+// ---- AR residual r_it = v_it - sum_l Theta_lt v_{i-L_l,t}  (trmf.cpp:110-113 / 136-139) ------------
+// One thread per (i, t); emits partial sums of r^2 (AR part of fun) and v^2 (ridge part of fun).
+// FUSE_DIR (top of CG iteration it >= 1, rf_tron.h:494-502): the operand is the NEW direction
+//   d_new = d + (beta-1) d + r,  beta = rho_cur / rho_prev,
+// recomputed on the fly wherever the stencil needs it and written once to `dnew` (ping-pong buffer).
+template <bool FUSE_DIR>
+__global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XState *__restrict__ st,
+                                                          const double *__restrict__ Prr_cur,
+                                                          const double *__restrict__ Prr_prev,
+                                                          int np, const real *__restrict__ v,
+                                                          const real *__restrict__ rvec,
+                                                          real *__restrict__ dnew,
+                                                          const uint32_t *__restrict__ lag_set,
+                                                          const real *__restrict__ theta,
+                                                          double *__restrict__ rAR,
+                                                          double *__restrict__ Pbase) {
+    __shared__ double smem[256];
+    real tmp = 0;
+    if (Prr_cur != nullptr) {
+        const real rho = (real)sum_partials(Prr_cur, np, smem);
+        if (cg_stopped(rho, st->cgtol)) return;
+        if (FUSE_DIR) {
+            const real rho_prev = (real)sum_partials(Prr_prev, np, smem);
+            const real beta = rho / rho_prev;                                // rf_tron.h:495
+            tmp = beta - (real)1.0;                                          // rf_tron.h:497
+        }
+    }
+    auto operand = [&](size_t e) -> real {
+        real dv = v[e];
+        if (FUSE_DIR) {
+            dv = fma(tmp, dv, dv);                                           // axpy(tmp, d, d)
+            dv = dv + rvec[e];                                               // axpy(1, r, d)
+        }
+        return dv;
+    };
+    const size_t N = (size_t)p.T * p.KP;
+    double ar2 = 0, vv = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e / p.KP), t = (int)(e - (size_t)i * p.KP);
+        const real x = operand(e);
+        if (FUSE_DIR) dnew[e] = x;
+        vv += (double)x * (double)x;
+        double res = 0;
+        if (t < p.k && i >= p.midx && p.nlag > 0) {
+            res = (double)x;
+            for (int l = 0; l < p.nlag; l++) {
+                const real prod = theta[(size_t)t * p.nlag + l] *
+                                  operand((size_t)(i - (int)lag_set[l]) * p.KP + t);
+                res -= (double)prod;
+            }
+            ar2 += res * res;
+        }
+        rAR[e] = res;
+    }
+    ar2 = block_allsum(ar2, smem);
+    vv = block_allsum(vv, smem);
+    if (threadIdx.x == 0) {
+        Pbase[P_AR * kMaxPartials + blockIdx.x] = ar2;
+        Pbase[P_VV * kMaxPartials + blockIdx.x] = vv;
+    }
+}
+
+// ---- out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b) ; partial of <dotwith, out> ----------------------
+// grad (trmf.cpp:99-123 + 247-267) when minus_b, Hessian-vector product (trmf.cpp:125-149 + 269-288)
+// otherwise.  One thread per (row, column); `rpb` rows per block; the row's v is staged in LDS.
+// dot_mode 0: <out,out>   1: <v,out>
+__global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__restrict__ st,
+                                                    const double *__restrict__ Prr_cur, int np,
+                                                    const real *__restrict__ v,
+                                                    const double *__restrict__ rAR,
+                                                    const uint32_t *__restrict__ lag_set,
+                                                    const real *__restrict__ theta,
+                                                    const real *__restrict__ G,
+                                                    const real *__restrict__ Bv, int minus_b,
+                                                    real *__restrict__ out, int dot_mode,
+                                                    double *__restrict__ Pdot, int rpb) {
+    __shared__ double smem[256];
+    __shared__ real vs[256];
+    if (Prr_cur != nullptr) {
+        const real rho = (real)sum_partials(Prr_cur, np, smem);
+        if (cg_stopped(rho, st->cgtol)) return;
+    }
+    const int k = p.k, KP = p.KP;
+    const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;
+    const bool active_lane = lr < rpb;
+    double dot = 0;
+    const int ngroups = (p.T + rpb - 1) / rpb;
+    for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+        const int i = grp * rpb + lr;
+        const bool active = active_lane && i < p.T;
+        real x = 0;
+        if (active) x = v[(size_t)i * KP + t];
+        __syncthreads();
+        vs[threadIdx.x] = x;
+        __syncthreads();
+        if (active) {
+            // base part: same rounding sequence as the reference's time-ordered scatter loop
+            real o;
+            if (p.lambdaI == 0) o = 0;
+            else if (p.lambdaI == 1) o = x;
+            else o = (real)(p.lambdaI * (double)x);
+            if (p.nlag > 0 && p.lambdaAR > 0) {
+                if (i >= p.midx) o = (real)((double)o + p.lambdaAR * rAR[(size_t)i * KP + t]);
+                for (int l = 0; l < p.nlag; l++) {
+                    const int ii = i + (int)lag_set[l];
+                    if (ii >= p.midx && ii < p.T)
+                        o = (real)((double)o - p.lambdaAR * rAR[(size_t)ii * KP + t] *
+                                                   (double)theta[(size_t)t * p.nlag + l]);
+                }
+            }
+            // cached Gram: sum_s G_i[s][t] * v_i[s]
+            const real *Gi = G + (size_t)i * k * k + t;
+            const real *vi = vs + lr * k;
+            double acc = 0;
+#pragma unroll 8
+            for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k] * (double)vi[s];
+            if (minus_b) acc -= (double)Bv[(size_t)i * KP + t];
+            o = (real)((double)o + acc);
+            out[(size_t)i * KP + t] = o;
+            dot += (double)(dot_mode ? x : o) * (double)o;
+        }
+    }
+    dot = block_allsum(dot, smem);
+    if (threadIdx.x == 0) Pdot[blockIdx.x] = dot;
+}
+
+// ---- CG initialisation: f, |g|, tolerances; s = 0, r = -g, d = r  (rf_tron.h:154-169, 424-439) ----
+__global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restrict__ st,
+                                                      double *__restrict__ Pbase, int np_base,
+                                                      int np_dot, const real *__restrict__ g,
+                                                      real *__restrict__ s, real *__restrict__ r,
+                                                      real *__restrict__ d) {
+    __shared__ double smem[256];
+    const double ar2 = sum_partials(Pbase + P_AR * kMaxPartials, np_base, smem);
+    const double vv = sum_partials(Pbase + P_VV * kMaxPartials, np_base, smem);
+    const double gg = sum_partials(Pbase + P_DOT * kMaxPartials, np_dot, smem);
+    const real ggr = (real)gg;                                               // BLAS dot in val_type
+    // rho[0] = r^T r = g^T g (rf_tron.h:439), published as a one-hot partial array
+    if (threadIdx.x == 0) Pbase[P_RR0 * kMaxPartials + blockIdx.x] = (blockIdx.x == 0) ? (double)ggr : 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double f = 0.5 * st->loss0;
+        if (p.lambdaI > 0) f += 0.5 * p.lambdaI * (double)(real)vv;          // trmf.cpp:73-75
+        if (p.nlag > 0 && p.lambdaAR > 0) f += 0.5 * p.lambdaAR * ar2;       // trmf.cpp:94
+        const double gnorm = sqrt((double)ggr);
+        st->f = f; st->fnew = f; st->gnorm = gnorm;
+        st->cgtol = (real)(p.eps_cg * gnorm);                                // rf_tron.h:434
+        st->cg_rnorm = gnorm;
+        st->cg_iter = 0;
+        st->accepted = 0;
+    }
+    const size_t N = (size_t)p.T * p.KP;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        const real gv = g[e];
+        s[e] = 0; r[e] = -gv; d[e] = -gv;
+    }
+}
+
+// ---- alpha = rho / <d,Hd>; s += alpha d; r -= alpha Hd; partial <r,r> -> rho[it+1] -----------------
+// (rf_tron.h:456-494).  When the iteration is stopped the partials are forwarded unchanged.
+__global__ __launch_bounds__(256) void cg_update_kernel(XParams p, XState *__restrict__ st,
+                                                        const double *__restrict__ Prr_cur,
+                                                        double *__restrict__ Prr_next,
+                                                        const double *__restrict__ PdHd, int np,
+                                                        int np_dHd, int it,
+                                                        const real *__restrict__ d,
+                                                        const real *__restrict__ Hd,
+                                                        real *__restrict__ s, real *__restrict__ r) {
+    __shared__ double smem[256];
+    const real rho = (real)sum_partials(Prr_cur, np, smem);
+    if (cg_stopped(rho, st->cgtol)) {
+        if (threadIdx.x == 0) Prr_next[blockIdx.x] = Prr_cur[blockIdx.x];
+        return;
+    }
+    const real dHd = (real)sum_partials(PdHd, np_dHd, smem);
+    const real alpha = rho / dHd;                                            // rf_tron.h:460
+    const real nalpha = -alpha;
+    const size_t N = (size_t)p.T * p.KP;
+    double rr = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        s[e] = fma(alpha, d[e], s[e]);
+        const real rv = fma(nalpha, Hd[e], r[e]);
+        r[e] = rv;
+        rr += (double)rv * (double)rv;
+    }
+    rr = block_allsum(rr, smem);
+    if (threadIdx.x == 0) {
+        Prr_next[blockIdx.x] = rr;
+        if (blockIdx.x == 0) st->cg_iter = it + 1;      // nobody reads cg_iter during the solve
+    }
+}
+
+// ---- w_new = w + s ; partials <g,s>, <s,r>  (rf_tron.h:183-190) --------------------------------------
+__global__ __launch_bounds__(256) void wnew_kernel(XParams p, const real *__restrict__ w,
+                                                   const real *__restrict__ s,
+                                                   const real *__restrict__ g,
+                                                   const real *__restrict__ r,
+                                                   real *__restrict__ w_new,
+                                                   double *__restrict__ Pbase) {
+    __shared__ double smem[256];
+    const size_t N = (size_t)p.T * p.KP;
+    double gs = 0, sr = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        const real sv = s[e];
+        w_new[e] = w[e] + sv;
+        gs += (double)g[e] * (double)sv;
+        sr += (double)sv * (double)r[e];
+    }
+    gs = block_allsum(gs, smem);
+    sr = block_allsum(sr, smem);
+    if (threadIdx.x == 0) {
+        Pbase[P_GS * kMaxPartials + blockIdx.x] = gs;
+        Pbase[P_SR * kMaxPartials + blockIdx.x] = sr;
+    }
+}
+
+// ---- acceptance test and commit (rf_tron.h:191-229) -------------------------------------------------
+// Every block derives the same decision; block 0 records the TRON line values.
+__global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restrict__ st,
+                                                     const double *__restrict__ Pbase, int np,
+                                                     const double *__restrict__ Prr_final,
+                                                     const real *__restrict__ w_new,
+                                                     real *__restrict__ w) {
+    __shared__ double smem[256];
+    const double ar2 = sum_partials(Pbase + P_AR * kMaxPartials, np, smem);
+    const double vv = sum_partials(Pbase + P_VV * kMaxPartials, np, smem);
+    const double gs = (double)(real)sum_partials(Pbase + P_GS * kMaxPartials, np, smem);
+    const double sr = (double)(real)sum_partials(Pbase + P_SR * kMaxPartials, np, smem);
+    const double rho = (double)(real)sum_partials(Prr_final, np, smem);
+    double fnew = 0.5 * st->loss1;
+    if (p.lambdaI > 0) fnew += 0.5 * p.lambdaI * (double)(real)vv;
+    if (p.nlag > 0 && p.lambdaAR > 0) fnew += 0.5 * p.lambdaAR * ar2;
+    const double f = st->f;
+    const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190
+    const double actred = f - fnew;
+    const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
+    if (accept) {
+        const size_t N = (size_t)p.T * p.KP;
+        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256)
+            w[e] = w_new[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // fields no block reads in this kernel
+        st->fnew = fnew; st->gs = gs; st->sr = sr;
+        st->prered = prered; st->actred = actred;
+        st->accepted = accept ? 1 : 0;
+        st->cg_rnorm = sqrt(rho);
+    }
+}
+
+}  // namespace trmf

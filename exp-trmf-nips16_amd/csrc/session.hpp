@@ -1,0 +1,413 @@
+// session.hpp -- host side of the MI355X TRMF solver: HBM-resident problem state and the outer ALS
+// loop (trmf.cpp:599-694) expressed as asynchronous kernel launches on one HIP stream.
+//
+// HBM layout (all resident for the lifetime of a session):
+//   Yc_*   CSC of Y viewed as CSR over items   (F-solve rows):  ptr u32[n+1], idx u32[nnz], val[nnz]
+//   Yr_*   CSR of Y over timestamps            (X-side rows):   ptr u32[T+1], idx u32[nnz], val[nnz]
+//   W      T x KP, H  n x KP   (KP = k rounded up to 16, zero padded, row-major)
+//   theta  |L| x k column-major (as the ABI delivers it)
+//   G      T x k x k   cached per-timestamp Gram,  Bv  T x KP rhs,  lossrow  T doubles
+//   CG     g, s, r, d0, d1, Hd, w_new: T x KP each; rAR: T x KP doubles; partial-sum arrays
+//
+// With several ranks (one process per GPU) the nnz-heavy kernels (F-solve, X-side Gram, loss) run
+// on this rank's contiguous row block and the results are all-gathered; the CG itself runs
+// replicated and bit-identical on every rank (DESIGN.md "Multi-GPU").
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/trmf_abi.h"
+#include "cg_kernels.hpp"
+#include "comm.hpp"
+#include "common.hpp"
+#include "gram_kernels.hpp"
+#include "theta_kernels.hpp"
+
+namespace trmf {
+
+Comm *active_comm();   // trmf_abi.hip
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    int alloc(size_t count, bool zero = true) {
+        release();
+        n = count;
+        TRMF_HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
+        if (zero) TRMF_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+        return 0;
+    }
+    int upload(const T *src, size_t count) {
+        if (alloc(count, false)) return kFail;
+        if (count) TRMF_HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+struct DeviceIterLog {       // one per ALS iteration, filled on device
+    double normF, normX, normLV;
+    XState x;
+};
+
+struct PhaseEvents { hipEvent_t f0, fk0, fk1, f1, x1, lv1; };
+
+struct TrmfSessionImpl {
+    // problem
+    int T = 0, n = 0, k = 0, KP = 0, NT = 0, KMAX = 0, nlag = 0, midx = 0;
+    uint64_t nnz = 0;
+    double lambdaI = 0, lambdaAR = 0, lambdaLag = 0;
+    int period_W = 1, period_H = 1, period_Lag = 2, verbose = 0;
+    int max_cg_iter = 20;        // 10 * 2, trmf.h:90-93 folded by trmf.cpp:603-606
+    double eps_cg = 0.1;
+    int iter = 0;                // ALS iterations done so far
+    // distribution
+    Comm *comm = nullptr;
+    std::vector<uint64_t> fbounds, xbounds;   // row partitions of items / timestamps
+    // device
+    hipStream_t stream = nullptr;
+    DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set;
+    DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, d0, d1, Hd, w_new;
+    DevBuf<double> rAR, lossrow, partials, theta_part;
+    DevBuf<XState> xstate;
+    DevBuf<DeviceIterLog> log;
+    static constexpr int kLogCap = 4096;
+    std::vector<PhaseEvents> events;
+    static constexpr int kEventRing = 64;
+    int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
+    XParams xp{};
+
+    ~TrmfSessionImpl() {
+        for (auto &e : events) {
+            hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.x1, e.lv1};
+            for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
+        }
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    double *P(int slot) { return partials.p + (size_t)slot * kMaxPartials; }
+
+    // ---------------------------------------------------------------------------------------------
+    int upload_padded(DevBuf<real> &dst, const real *src, size_t rows) {
+        std::vector<real> tmp(rows * (size_t)KP, real(0));
+        for (size_t i = 0; i < rows; i++) std::memcpy(&tmp[i * KP], src + i * (size_t)k, sizeof(real) * k);
+        return dst.upload(tmp.data(), tmp.size());
+    }
+    int download_padded(const DevBuf<real> &src, real *dst, size_t rows) {
+        std::vector<real> tmp(rows * (size_t)KP);
+        if (tmp.size()) TRMF_HIP_CHECK(hipMemcpy(tmp.data(), src.p, tmp.size() * sizeof(real), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < rows; i++) std::memcpy(dst + i * (size_t)k, &tmp[i * KP], sizeof(real) * k);
+        return 0;
+    }
+    static int upload_ptr32(DevBuf<uint32_t> &dst, const size_t *src, size_t count) {
+        std::vector<uint32_t> tmp(count);
+        for (size_t i = 0; i < count; i++) tmp[i] = (uint32_t)src[i];
+        return dst.upload(tmp.data(), count);
+    }
+
+    int create(const PyMatrix *Y, const uint32_t *lags, uint32_t lag_size, const PyMatrix *Wm,
+               const PyMatrix *Hm, const PyMatrix *LVm) {
+        T = (int)Y->rows; n = (int)Y->cols; k = (int)Wm->cols; nnz = Y->nnz;
+        KP = padded_rank(k); NT = KP / kTile; KMAX = ((k + 7) / 8) * 8;
+        nlag = (int)lag_size; midx = nlag ? (int)lags[nlag - 1] : 0;
+        comm = active_comm();
+        host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
+        TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+
+        if (upload_ptr32(Yr_ptr, Y->row_ptr, (size_t)T + 1)) return kFail;
+        if (Yr_idx.upload(Y->col_idx, nnz)) return kFail;
+        if (Yr_val.upload((const real *)Y->val_t, nnz)) return kFail;
+        if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
+        if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
+        if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
+        if (lag_set.upload(lags, nlag)) return kFail;
+        if (upload_padded(W, (const real *)Wm->val, T)) return kFail;
+        if (upload_padded(H, (const real *)Hm->val, n)) return kFail;
+        if (theta.upload((const real *)LVm->val, (size_t)nlag * k)) return kFail;
+
+        const size_t NV = (size_t)T * KP;
+        if (G.alloc((size_t)T * k * k) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
+            d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
+            lossrow.alloc(T) || partials.alloc((size_t)P_NSLOTS * kMaxPartials) || xstate.alloc(1) ||
+            log.alloc(kLogCap))
+            return kFail;
+        const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
+        const int npairs = nlag * (nlag + 1) / 2 + nlag;
+        if (theta_part.alloc((size_t)k * nchunk * std::max(npairs, 1))) return kFail;
+
+        nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
+        rpb = std::max(1, 256 / k);
+        nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
+        xp.T = T; xp.k = k; xp.KP = KP; xp.nlag = nlag; xp.midx = midx;
+        xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
+
+        fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1);
+        partition_by_nnz<size_t>((uint64_t)n, Y->col_ptr, comm->world, fbounds.data());
+        partition_by_nnz<size_t>((uint64_t)T, Y->row_ptr, comm->world, xbounds.data());
+
+        events.resize(kEventRing);
+        for (auto &e : events) {
+            hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
+            for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
+        }
+        TRMF_HIP_CHECK(hipDeviceSynchronize());
+        return 0;
+    }
+
+    // ---- all-gather helpers ------------------------------------------------------------------------
+    int gather_rows(void *dbuf, const std::vector<uint64_t> &bounds, size_t row_bytes) {
+        if (comm->world == 1) return 0;
+        std::vector<uint64_t> off(bounds.size());
+        for (size_t i = 0; i < bounds.size(); i++) off[i] = bounds[i] * row_bytes;
+        return comm->allgatherv(dbuf, off.data(), stream);
+    }
+
+    // ---- F-solve (trmf.cpp:654-663 -> 369-397) -------------------------------------------------------
+    template <int NT_, int KMAX_> int launch_fsolve(uint32_t rb, uint32_t re) {
+        const uint32_t rows = re - rb;
+        if (rows == 0) return 0;
+        hipLaunchKernelGGL((fsolve_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
+                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI);
+        return 0;
+    }
+    int fsolve(PhaseEvents &ev) {
+        const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
+        TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        switch (KMAX) {
+            case 8:  launch_fsolve<1, 8>(rb, re); break;
+            case 16: launch_fsolve<1, 16>(rb, re); break;
+            case 24: launch_fsolve<2, 24>(rb, re); break;
+            case 32: launch_fsolve<2, 32>(rb, re); break;
+            case 40: launch_fsolve<3, 40>(rb, re); break;
+            case 48: launch_fsolve<3, 48>(rb, re); break;
+            case 56: launch_fsolve<4, 56>(rb, re); break;
+            case 64: launch_fsolve<4, 64>(rb, re); break;
+            default: set_error("unsupported rank"); return kFail;
+        }
+        TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+        TRMF_HIP_CHECK(hipGetLastError());
+        return gather_rows(H.p, fbounds, (size_t)KP * sizeof(real));
+    }
+
+    // ---- X-side Gram cache / loss ---------------------------------------------------------------------
+    template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
+        if (re > rb)
+            hipLaunchKernelGGL((gram_x_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
+                               Yr_val.p, H.p, W.p, G.p, Bv.p, lossrow.p, rb, re, k);
+    }
+    template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
+        if (re > rb)
+            hipLaunchKernelGGL((loss_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
+                               Yr_val.p, H.p, Wv, lossrow.p, rb, re);
+    }
+    int gram_x() {
+        const uint32_t rb = (uint32_t)xbounds[comm->rank], re = (uint32_t)xbounds[comm->rank + 1];
+        switch (NT) {
+            case 1: launch_gram_x<1>(rb, re); break;
+            case 2: launch_gram_x<2>(rb, re); break;
+            case 3: launch_gram_x<3>(rb, re); break;
+            default: launch_gram_x<4>(rb, re); break;
+        }
+        TRMF_HIP_CHECK(hipGetLastError());
+        if (gather_rows(G.p, xbounds, (size_t)k * k * sizeof(real))) return kFail;
+        if (gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
+        return gather_rows(lossrow.p, xbounds, sizeof(double));
+    }
+    int loss(const real *Wv, bool all_rows) {
+        const uint32_t rb = all_rows ? 0u : (uint32_t)xbounds[comm->rank];
+        const uint32_t re = all_rows ? (uint32_t)T : (uint32_t)xbounds[comm->rank + 1];
+        switch (NT) {
+            case 1: launch_loss<1>(Wv, rb, re); break;
+            case 2: launch_loss<2>(Wv, rb, re); break;
+            case 3: launch_loss<3>(Wv, rb, re); break;
+            default: launch_loss<4>(Wv, rb, re); break;
+        }
+        TRMF_HIP_CHECK(hipGetLastError());
+        return all_rows ? 0 : gather_rows(lossrow.p, xbounds, sizeof(double));
+    }
+
+    // ---- X-solve (trmf.cpp:665-674 -> rf_tron.h:134-254) -----------------------------------------------
+    int xsolve() {
+        XState *st = xstate.p;
+        double *Pb = partials.p;
+        if (gram_x()) return kFail;                                            // G, b, loss(w)
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss0);
+        hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st,
+                           (const double *)nullptr, (const double *)nullptr, 0, W.p, (const real *)nullptr,
+                           (real *)nullptr, lag_set.p, theta.p, rAR.p, Pb);
+        hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, (const double *)nullptr, 0,
+                           W.p, rAR.p, lag_set.p, theta.p, G.p, Bv.p, 1, g.p, 0, P(P_DOT), rpb);
+        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, g.p, s.p,
+                           r.p, d0.p);
+        const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
+        real *dcur = d0.p, *dalt = d1.p;
+        for (int it = 0; it < maxcg; it++) {
+            double *Pcur = P(P_RR0 + (it & 1)), *Pnext = P(P_RR0 + ((it + 1) & 1));
+            if (it == 0) {
+                hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur,
+                                   (const double *)nullptr, nbe, dcur, (const real *)nullptr, (real *)nullptr,
+                                   lag_set.p, theta.p, rAR.p, Pb);
+            } else {
+                hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur,
+                                   Pnext /* = rho[it-1] */, nbe, dcur, r.p, dalt, lag_set.p, theta.p, rAR.p, Pb);
+                std::swap(dcur, dalt);
+            }
+            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, dcur, rAR.p,
+                               lag_set.p, theta.p, G.p, Bv.p, 0, Hd.p, 1, P(P_DOT), rpb);
+            hipLaunchKernelGGL(cg_update_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pnext, P(P_DOT),
+                               nbe, nba, it, dcur, Hd.p, s.p, r.p);
+        }
+        double *Pfinal = P(P_RR0 + (maxcg & 1));
+        hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, W.p, s.p, g.p, r.p, w_new.p, Pb);
+        hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st,
+                           (const double *)nullptr, (const double *)nullptr, 0, w_new.p, (const real *)nullptr,
+                           (real *)nullptr, lag_set.p, theta.p, rAR.p, Pb);
+        if (loss(w_new.p, false)) return kFail;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss1);
+        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, Pfinal, w_new.p, W.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+
+    // ---- Theta solve (trmf.cpp:677-689 -> 455-484) ------------------------------------------------------
+    int theta_solve() {
+        if (nlag == 0) return 0;
+        const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
+        const int npairs = nlag * (nlag + 1) / 2 + nlag;
+        const size_t lds1 = (size_t)(kThetaChunk + midx) * sizeof(real);
+        hipLaunchKernelGGL(theta_gram_kernel, dim3(k, nchunk), dim3(256), lds1, stream, W.p, T, KP, lag_set.p,
+                           nlag, midx, npairs, theta_part.p);
+        const size_t lds2 = (size_t)(nlag * nlag + nlag) * sizeof(real);
+        hipLaunchKernelGGL(theta_solve_kernel, dim3(k), dim3(64), lds2, stream, theta_part.p, nchunk, nlag,
+                           npairs, lambdaLag, theta.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+
+    // ---- ||.||^2 into a log slot ----------------------------------------------------------------------------
+    int log_norm(const real *v, size_t count, double *dst) {
+        const int nb = (int)std::min<size_t>(kMaxPartials, (count + 255) / 256);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, v, count, P(P_DOT));
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_DOT), nb, dst);
+        return 0;
+    }
+
+    double host_double(const double *dptr) {
+        double v = 0;
+        (void)hipStreamSynchronize(stream);
+        (void)hipMemcpy(&v, dptr, sizeof(double), hipMemcpyDeviceToHost);
+        return v;
+    }
+
+    // ---- the ALS loop (trmf.cpp:647-693) --------------------------------------------------------------------
+    int run(int iters) {
+        for (int it = 0; it < iters; it++) {
+            const int iter1 = ++iter;                       // 1-based like the reference
+            DeviceIterLog *L = log.p + ((iter1 - 1) % kLogCap);
+            PhaseEvents &ev = events[(iter1 - 1) % kEventRing];
+            static const DeviceIterLog blank = [] { DeviceIterLog b; std::memset(&b, 0, sizeof b); b.normF = b.normX = b.normLV = -1; return b; }();
+            TRMF_HIP_CHECK(hipMemcpyAsync(L, &blank, sizeof blank, hipMemcpyHostToDevice, stream));
+            TRMF_HIP_CHECK(hipEventRecord(ev.f0, stream));
+            const bool doF = period_H > 0 && (iter1 % period_H) == 0;
+            const bool doX = period_W > 0 && (iter1 % period_W) == 0;
+            const bool doL = period_Lag > 0 && (iter1 % period_Lag) == 0;
+            if (doF) {
+                if (fsolve(ev)) return kFail;
+                log_norm(H.p, (size_t)n * KP, &L->normF);
+                if (verbose) fprintf(stderr, ">> iter %d F %g\n", iter1, host_double(&L->normF));
+            } else {
+                TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+                TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+            }
+            TRMF_HIP_CHECK(hipEventRecord(ev.f1, stream));
+            if (doX) {
+                if (xsolve()) return kFail;
+                log_norm(W.p, (size_t)T * KP, &L->normX);
+                TRMF_HIP_CHECK(hipMemcpyAsync(&L->x, xstate.p, sizeof(XState), hipMemcpyDeviceToDevice, stream));
+                if (verbose) {
+                    fprintf(stderr, ">> iter %d X %g\n", iter1, host_double(&L->normX));
+                    if (verbose >= 2) {
+                        XState hx;
+                        (void)hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost);
+                        fprintf(stdout, "iter  1 act %5.3e pre %5.3e delta %5.3e f %5.3e |g| %5.3e CG %3d |g| %5.3e\n",
+                                hx.actred, hx.prered, hx.gnorm, hx.f, hx.gnorm, hx.cg_iter, hx.cg_rnorm);
+                        fflush(stdout);
+                    }
+                }
+            }
+            TRMF_HIP_CHECK(hipEventRecord(ev.x1, stream));
+            if (doL) {
+                if (verbose) {
+                    log_norm(theta.p, (size_t)nlag * k, &L->normLV);
+                    fprintf(stderr, ">> iter %d LV(%d %d) %g\n", iter1, nlag, k, host_double(&L->normLV));
+                }
+                if (theta_solve()) return kFail;
+                log_norm(theta.p, (size_t)nlag * k, &L->normLV);
+                if (verbose) fprintf(stderr, ">> iter %d LV %g\n", iter1, host_double(&L->normLV));
+            }
+            TRMF_HIP_CHECK(hipEventRecord(ev.lv1, stream));
+        }
+        return 0;
+    }
+
+    int sync() { TRMF_HIP_CHECK(hipStreamSynchronize(stream)); return 0; }
+
+    int stats(TrmfIterStats *out, int cap) {
+        if (sync()) return kFail;
+        const int avail = std::min(iter, std::min(kLogCap, kEventRing));
+        const int cnt = std::min(cap, avail);
+        for (int q = 0; q < cnt; q++) {
+            const int it0 = iter - cnt + q;                 // 0-based iteration index
+            DeviceIterLog hl;
+            TRMF_HIP_CHECK(hipMemcpy(&hl, log.p + (it0 % kLogCap), sizeof hl, hipMemcpyDeviceToHost));
+            PhaseEvents &ev = events[it0 % kEventRing];
+            TrmfIterStats &o = out[q];
+            o.normF = hl.normF; o.normX = hl.normX; o.normLV = hl.normLV;
+            o.f = hl.x.f; o.fnew = hl.x.fnew; o.actred = hl.x.actred; o.prered = hl.x.prered;
+            o.gnorm = hl.x.gnorm; o.cg_rnorm = hl.x.cg_rnorm; o.cg_iter = hl.x.cg_iter; o.accepted = hl.x.accepted;
+            o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = 0;
+            (void)hipEventElapsedTime(&o.ms_F, ev.f0, ev.f1);
+            (void)hipEventElapsedTime(&o.ms_F_kernel, ev.fk0, ev.fk1);
+            (void)hipEventElapsedTime(&o.ms_X, ev.f1, ev.x1);
+            (void)hipEventElapsedTime(&o.ms_LV, ev.x1, ev.lv1);
+        }
+        return cnt;
+    }
+
+    // J = 0.5*sum_Omega (Y - w.h)^2 + 0.5*lambdaI(|W|^2+|H|^2) + 0.5*lambdaAR*AR(W;Theta)  
+    double objective() {
+        XState *st = xstate.p;
+        if (loss(W.p, true)) return NAN;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss1);
+        const double l = host_double(&st->loss1);
+        hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st,
+                           (const double *)nullptr, (const double *)nullptr, 0, W.p, (const real *)nullptr,
+                           (real *)nullptr, lag_set.p, theta.p, rAR.p, partials.p);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_AR), nbe, &st->gs);
+        const double ar = host_double(&st->gs);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_VV), nbe, &st->gs);
+        const double w2 = host_double(&st->gs);
+        log_norm(H.p, (size_t)n * KP, &st->gs);
+        const double h2 = host_double(&st->gs);
+        return 0.5 * l + 0.5 * lambdaI * (w2 + h2) + 0.5 * lambdaAR * ar;
+    }
+
+    // algorithmic bytes of one F-solve launch on this rank
+    double fsolve_bytes() const { return bytes_for_rows(fbounds[comm->rank], fbounds[comm->rank + 1]); }
+    std::vector<uint64_t> host_col_ptr;   // kept for fsolve_bytes
+    double bytes_for_rows(uint64_t rb, uint64_t re) const {
+        const double sz = sizeof(real);
+        const double nz = host_col_ptr.empty() ? 0.0 : (double)(host_col_ptr[re] - host_col_ptr[rb]);
+        const double rows = (double)(re - rb);
+        return nz * (4.0 + sz + k * sz) + (rows + 1) * 8.0 + rows * k * sz;
+    }
+};
+
+}  // namespace trmf

@@ -1,0 +1,242 @@
+// trmf_abi.hip -- extern "C" entry points of trmf_float{32,64}.so (see include/trmf_abi.h).
+//
+// Section 1: c_trmf_train, the reference's own boundary (trmf.h:203-210, trmf.cpp:696-725).
+// Section 2: build-owned session / device / multi-GPU entry points.
+//
+// There is deliberately no host implementation of the solver behind these symbols: if the HIP
+// runtime reports no usable device the calls fail loudly.
+#include "../../include/trmf_abi.h"
+
+#include <memory>
+#include <mutex>
+
+#include "session.hpp"
+
+namespace trmf {
+
+static std::string g_last_error = "";
+static std::mutex g_err_mu;
+void set_error(const std::string &msg) {
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    g_last_error = msg;
+}
+
+static int g_device = 0;
+static SelfComm g_self;
+static std::unique_ptr<Comm> g_comm;
+Comm *active_comm() { return g_comm ? g_comm.get() : &g_self; }
+
+static bool bind_device() {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+        set_error("no HIP device visible (the MI355X TRMF solver has no CPU fallback)");
+        return false;
+    }
+    if (hipSetDevice(g_device) != hipSuccess) {
+        set_error("hipSetDevice failed");
+        return false;
+    }
+    return true;
+}
+
+// check_dimension, trmf.cpp:561-596 (same messages, same order)
+static bool check_dimension(const PyMatrix *Y, const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
+                            uint32_t lag_size) {
+    bool pass = true;
+    if (Y->rows != W->rows) { fprintf(stderr, "[ERR MSG]: Y.rows (%ld) != W.rows (%ld)\n", (long)Y->rows, (long)W->rows); pass = false; }
+    if (Y->cols != H->rows) { fprintf(stderr, "[ERR MSG]: Y.cols (%ld) != H.rows (%ld)\n", (long)Y->cols, (long)H->rows); pass = false; }
+    if (W->cols != H->cols) { fprintf(stderr, "[ERR MSG]: W.cols (%ld) != H.cols (%ld)\n", (long)W->cols, (long)H->cols); pass = false; }
+    if (lag_size != LV->rows) { fprintf(stderr, "[ERR MSG]: lag_set.size(%ld) != lag_val.rows(%ld)\n", (long)lag_size, (long)LV->rows); pass = false; }
+    if (W->cols != LV->cols) { fprintf(stderr, "[ERR MSG]: W.cols(%ld) != lag_val.cols(%ld)\n", (long)W->cols, (long)LV->cols); pass = false; }
+    if (W->type != TRMF_DENSE_ROWMAJOR) { fprintf(stderr, "[ERR MSG]: W should be rowmajored\n"); pass = false; }
+    if (H->type != TRMF_DENSE_ROWMAJOR) { fprintf(stderr, "[ERR MSG]: H should be rowmajored\n"); pass = false; }
+    if (LV->type != TRMF_DENSE_COLMAJOR) { fprintf(stderr, "[ERR MSG]: lag_val should be colmajored\n"); pass = false; }
+    return pass;
+}
+
+// Limits of the device path (documented in DESIGN.md); violations are reported, never worked around.
+static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t lag_size, int missing) {
+    bool pass = true;
+    if (!missing) { fprintf(stderr, "[ERR MSG]: missing=0 (full-observation path) is not implemented on the MI355X path yet\n"); pass = false; }
+    if (missing && Y->type != TRMF_SPARSE) { fprintf(stderr, "[ERR MSG]: missing!=0 requires a sparse Y\n"); pass = false; }
+    if (W->cols < 1 || W->cols > (uint64_t)kMaxRank) { fprintf(stderr, "[ERR MSG]: rank k=%ld outside the supported range 1..%d\n", (long)W->cols, kMaxRank); pass = false; }
+    if (lag_size > (uint32_t)kMaxLags) { fprintf(stderr, "[ERR MSG]: |lag_set|=%u exceeds the supported %d\n", lag_size, kMaxLags); pass = false; }
+    if (Y->nnz >= (1ull << 32) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
+    return pass;
+}
+
+static TrmfSessionImpl *make_session(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
+                                     const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
+                                     double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
+                                     int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
+    if (!check_dimension(Y, W, H, LV, lag_size)) { set_error("dimension check failed"); return nullptr; }
+    if (!check_device_limits(Y, W, lag_size, missing)) { set_error("unsupported problem"); return nullptr; }
+    for (uint32_t l = 1; l < lag_size; l++)
+        if (lag_set[l] < lag_set[l - 1]) { fprintf(stderr, "[ERR MSG]: lag_set must be ascending\n"); set_error("lag_set not ascending"); return nullptr; }
+    if (lag_size && lag_set[lag_size - 1] >= Y->rows) { fprintf(stderr, "[ERR MSG]: max lag >= number of timestamps\n"); set_error("lag too large"); return nullptr; }
+    if (!bind_device()) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+    std::unique_ptr<TrmfSessionImpl> s(new TrmfSessionImpl());
+    s->lambdaI = lambdaI; s->lambdaAR = lambdaAR; s->lambdaLag = lambdaLag;
+    s->period_W = period_W; s->period_H = period_H; s->period_Lag = period_Lag; s->verbose = verbose;
+    if (s->create(Y, lag_set, lag_size, W, H, LV)) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+    return s.release();
+}
+
+}  // namespace trmf
+
+using namespace trmf;
+
+extern "C" {
+
+struct TrmfSession { TrmfSessionImpl impl; };   // opaque to callers; never instantiated as such
+
+// ------------------------------------------------------------------------------------------------
+// Section 1
+// ------------------------------------------------------------------------------------------------
+void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_size, PyMatrix *pyW,
+                  PyMatrix *pyH, PyMatrix *pylag_val, int warm_start, double lambdaI, double lambdaAR,
+                  double lambdaLag, int32_t max_iter, int32_t period_W, int32_t period_H,
+                  int32_t period_Lag, int32_t threads, int32_t missing, int32_t verbose) {
+    if (verbose > 0) {   // parameter dump, trmf.cpp:607-629 (after the fold of :603-606)
+        fprintf(stdout, ">> param.solver_type %d\n", missing ? 31 : 30);
+        fprintf(stdout, ">> param.max_iter %d\n", max_iter);
+        fprintf(stdout, ">> param.lambdaI %g\n", lambdaI);
+        fprintf(stdout, ">> param.lambdaAR %g\n", lambdaAR);
+        fprintf(stdout, ">> param.lambdaLag %g\n", lambdaLag);
+        fprintf(stdout, ">> param.period_W %d\n", period_W);
+        fprintf(stdout, ">> param.period_H %d\n", period_H);
+        fprintf(stdout, ">> param.period_Lag %d\n", period_Lag);
+        fprintf(stdout, ">> param.threads %d\n", threads);
+        fprintf(stdout, ">> param.verbose %d\n", verbose);
+        fprintf(stdout, ">> param.eps %g\n", 0.1);
+        fprintf(stdout, ">> param.eps_cg %g\n", 0.1);
+        fprintf(stdout, ">> param.max_tron_iter %d\n", 1);
+        fprintf(stdout, ">> param.max_cg_iter %d\n", 20);
+        fprintf(stdout, ">> prob.lag_size %ld:  ", (long)py_lag_size);
+        for (uint32_t i = 0; i < py_lag_size; i++) fprintf(stdout, " %d", (int)py_lag_set[i]);
+        fprintf(stdout, "\n");
+        fflush(stdout);
+    }
+    // Quirk Q1: with warm_start == 0 the reference trains on private copies and the
+    // caller's arrays come back unchanged (trmf.cpp:552-558).  Observable behaviour reproduced.
+    if (!warm_start) return;
+    TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
+                                      lambdaLag, period_W, period_H, period_Lag, missing, verbose);
+    if (!s) return;                                  // diagnostics already on stderr; outputs untouched
+    int rc = s->run(max_iter);
+    if (rc == 0) rc = s->sync();
+    if (rc == 0) rc = s->download_padded(s->W, (real *)pyW->val, s->T);
+    if (rc == 0) rc = s->download_padded(s->H, (real *)pyH->val, s->n);
+    if (rc == 0 && s->nlag)
+        rc = hipMemcpy(pylag_val->val, s->theta.p, sizeof(real) * (size_t)s->nlag * s->k, hipMemcpyDeviceToHost) == hipSuccess ? 0 : kFail;
+    if (rc != 0) fprintf(stderr, "[ERR MSG]: device failure: %s\n", trmf_last_error());
+    delete s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Section 2
+// ------------------------------------------------------------------------------------------------
+int32_t trmf_sizeof_real(void) { return (int32_t)sizeof(real); }
+
+int32_t trmf_device_count(void) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) return 0;
+    return cnt;
+}
+
+int32_t trmf_set_device(int32_t device) {
+    int cnt = trmf_device_count();
+    if (device < 0 || device >= cnt) { set_error("device index out of range"); return kFail; }
+    g_device = device;
+    return hipSetDevice(device) == hipSuccess ? 0 : kFail;
+}
+
+const char *trmf_last_error(void) {
+    static thread_local std::string copy;
+    std::lock_guard<std::mutex> lk(g_err_mu);
+    copy = g_last_error;
+    return copy.c_str();
+}
+
+TrmfSession *trmf_session_create(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
+                                 const PyMatrix *W, const PyMatrix *H, const PyMatrix *lag_val,
+                                 double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
+                                 int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
+    return reinterpret_cast<TrmfSession *>(make_session(Y, lag_set, lag_size, W, H, lag_val, lambdaI, lambdaAR,
+                                                        lambdaLag, period_W, period_H, period_Lag, missing, verbose));
+}
+#define IMPL(s) reinterpret_cast<TrmfSessionImpl *>(s)
+
+int32_t trmf_session_run(TrmfSession *s, int32_t iters) { return s ? IMPL(s)->run(iters) : kFail; }
+int32_t trmf_session_sync(TrmfSession *s) { return s ? IMPL(s)->sync() : kFail; }
+
+int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val) {
+    if (!s) return kFail;
+    TrmfSessionImpl *t = IMPL(s);
+    if (t->sync()) return kFail;
+    if (W && (W->rows != (uint64_t)t->T || W->cols != (uint64_t)t->k || W->type != TRMF_DENSE_ROWMAJOR)) { set_error("W shape/layout mismatch"); return kFail; }
+    if (H && (H->rows != (uint64_t)t->n || H->cols != (uint64_t)t->k || H->type != TRMF_DENSE_ROWMAJOR)) { set_error("H shape/layout mismatch"); return kFail; }
+    if (lag_val && (lag_val->rows != (uint64_t)t->nlag || lag_val->cols != (uint64_t)t->k || lag_val->type != TRMF_DENSE_COLMAJOR)) { set_error("lag_val shape/layout mismatch"); return kFail; }
+    if (W && t->download_padded(t->W, (real *)W->val, t->T)) return kFail;
+    if (H && t->download_padded(t->H, (real *)H->val, t->n)) return kFail;
+    if (lag_val && t->nlag)
+        TRMF_HIP_CHECK(hipMemcpy(lag_val->val, t->theta.p, sizeof(real) * (size_t)t->nlag * t->k, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int32_t trmf_session_stats(TrmfSession *s, TrmfIterStats *out, int32_t cap) {
+    return (s && out && cap > 0) ? IMPL(s)->stats(out, cap) : 0;
+}
+double trmf_session_objective(TrmfSession *s) { return s ? IMPL(s)->objective() : NAN; }
+double trmf_session_fsolve_bytes(TrmfSession *s) { return s ? IMPL(s)->fsolve_bytes() : 0.0; }
+void trmf_session_destroy(TrmfSession *s) {
+    if (!s) return;
+    (void)IMPL(s)->sync();
+    delete IMPL(s);
+}
+
+// ---- multi-GPU ----------------------------------------------------------------------------------
+int32_t trmf_dist_get_unique_id(void *out_id) {
+    RcclApi &api = rccl_api();
+    if (!api.load()) return kFail;
+    RcclApi::UniqueId id;
+    const int rc = api.GetUniqueId(&id);
+    if (rc != 0) { set_error(std::string("ncclGetUniqueId: ") + api.GetErrorString(rc)); return kFail; }
+    std::memcpy(out_id, &id, TRMF_UNIQUE_ID_BYTES);
+    return 0;
+}
+
+int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id_bytes) {
+    if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world"); return kFail; }
+    if (!bind_device()) return kFail;
+    RcclApi &api = rccl_api();
+    if (!api.load()) return kFail;
+    RcclApi::UniqueId id;
+    std::memcpy(&id, id_bytes, TRMF_UNIQUE_ID_BYTES);
+    std::unique_ptr<RcclComm> c(new RcclComm());
+    c->rank = rank; c->world = world;
+    const int rc = api.CommInitRank(&c->comm, world, id, rank);
+    if (rc != 0) { set_error(std::string("ncclCommInitRank: ") + api.GetErrorString(rc)); c->comm = nullptr; return kFail; }
+    g_comm = std::move(c);
+    return 0;
+}
+
+int32_t trmf_dist_init_callback(int32_t rank, int32_t world, trmf_allgatherv_fn fn, void *ctx) {
+    if (world < 1 || rank < 0 || rank >= world || !fn) { set_error("bad rank/world/callback"); return kFail; }
+    std::unique_ptr<CallbackComm> c(new CallbackComm());
+    c->rank = rank; c->world = world; c->fn = fn; c->ctx = ctx;
+    g_comm = std::move(c);
+    return 0;
+}
+
+int32_t trmf_dist_rank(void) { return active_comm()->rank; }
+int32_t trmf_dist_world(void) { return active_comm()->world; }
+void trmf_dist_finalize(void) { g_comm.reset(); }
+
+int32_t trmf_partition_by_nnz(uint64_t nrows, const size_t *ptr, int32_t world, uint64_t *bounds) {
+    if (world < 1 || !ptr || !bounds) { set_error("bad arguments"); return kFail; }
+    partition_by_nnz<size_t>(nrows, ptr, world, bounds);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+"""Seeded synthetic TRMF workloads: low-rank + AR temporal structure,
+observed on a uniformly random sparse pattern.  Mirrors ``Model.syn_gen`` (reference
+python/trmf/trmf.py:195-220) without materialising the dense T x n matrix.
+
+Used by bench.py, the parity tests and the golden-vector script; pure NumPy/SciPy.
+"""
+import numpy as np
+import scipy.sparse as smat
+
+
+def sparse_problem(n, T, k, nlag, density, dtype=np.float32, seed=0, noise=0.01, chunk=1 << 20):
+    """Return dict(Y=csr T x n, lag_set=uint32[nlag], X, F, Theta) for a seeded synthetic problem."""
+    rng = np.random.RandomState(seed)
+    lag_set = np.arange(1, nlag + 1, dtype=np.uint32)
+    midx = int(lag_set[-1]) if nlag else 0
+    theta = rng.randn(nlag, k)
+    theta = theta / (np.abs(theta).sum(axis=0, keepdims=True) + 0.1)
+    X = np.zeros((T, k))
+    X[:max(midx, 1)] = rng.randn(max(midx, 1), k)
+    eps = noise * rng.randn(T, k)
+    lags = lag_set.astype(np.int64)
+    for i in range(max(midx, 1), T):
+        X[i] = (theta * X[i - lags]).sum(axis=0) + eps[i] if nlag else rng.randn(k)
+    F = rng.randn(n, k)
+    nnz0 = int(n * T * density)
+    rows = rng.randint(0, T, size=nnz0)
+    cols = rng.randint(0, n, size=nnz0)
+    vals = np.empty(nnz0)
+    for s in range(0, nnz0, chunk):
+        e = min(nnz0, s + chunk)
+        vals[s:e] = np.einsum('ij,ij->i', X[rows[s:e]], F[cols[s:e]])
+    vals += noise * rng.randn(nnz0)
+    Y = smat.coo_matrix((vals, (rows, cols)), shape=(T, n)).tocsr()   # duplicates are summed
+    Y.sort_indices()
+    return {'Y': Y.astype(dtype), 'lag_set': lag_set, 'X': X, 'F': F, 'Theta': theta}
+
+
+def initial_model(Y, lag_set, k, seed=0, dtype=None):
+    """``Model.initialize`` semantics (reference trmf.py:222-251): rand W, H; randn Theta (F order)."""
+    from .model import Model
+    return Model.initialize(Y, lag_set, k, seed=seed, dtype=dtype)
+
+
+# BASELINE.json configs (index = position in BASELINE.json:configs)
+CONFIGS = {
+    'c2': dict(n=10000, T=5000, k=16, nlag=8, density=0.01, dtype='float32'),
+    'c3': dict(n=100000, T=10000, k=40, nlag=16, density=0.01, dtype='float32'),
+    'c5': dict(n=1000000, T=50000, k=64, nlag=32, density=0.001, dtype='float64'),
+    # small shapes for tests
+    'tiny': dict(n=300, T=200, k=8, nlag=3, density=0.05, dtype='float32'),
+    'small40': dict(n=2000, T=600, k=40, nlag=16, density=0.03, dtype='float32'),
+}
+HYPER = dict(lambdaI=0.5, lambdaAR=50.0, lambdaLag=0.5)

@@ -1,0 +1,161 @@
+/*
+ * trmf_abi.h -- C ABI of the MI355X-native TRMF ALS solver (drop-in for rofuyu/exp-trmf-nips16).
+ *
+ * Two shared objects export this interface, one per element type, found by the reference's own
+ * loader glob (python/trmf/trmf.py:21-22,77-80; python/trmf/rf_util.py:19-32):
+ *
+ *     <pkg>/trmf/corelib/trmf_float32.so      (TRMF_REAL = float)
+ *     <pkg>/trmf/corelib/trmf_float64.so      (TRMF_REAL = double)
+ *
+ * Section 1 is the reference's boundary, byte-for-byte (every declaration cites the reference
+ * file:line it replaces).  Section 2 is build-owned (no reference counterpart): device control,
+ * a resident-session API so that callers can keep Y and the factors in HBM across calls
+ * (SURVEY.md section 8(f) rank 4, and what bench.py times), and the multi-GPU bootstrap.
+ *
+ * Everything is plain C: pointers, sizes, PODs.  No torch / C++ types cross this boundary.
+ * There is no CPU fallback behind it: if no HIP device is usable the entry points print a
+ * diagnostic on stderr and leave the outputs untouched (c_trmf_train is `void`, like the
+ * reference's) or return a negative error code (section 2).
+ */
+#ifndef TRMF_ABI_H
+#define TRMF_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+/* Only the entry points below are exported; everything else in the libraries has hidden
+ * visibility so that trmf_float32.so and trmf_float64.so can live in one process. */
+#if defined(__GNUC__) || defined(__clang__)
+#define TRMF_API __attribute__((visibility("default")))
+#else
+#define TRMF_API
+#endif
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Section 1 -- the reference boundary
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Matrix type tags: reference rf_matrix.h:3400-3405. */
+enum {
+    TRMF_DENSE_ROWMAJOR = 1,
+    TRMF_DENSE_COLMAJOR = 2,
+    TRMF_SPARSE = 3,
+    TRMF_EYE = 4
+};
+
+/* PyMatrix: reference rf_matrix.h:3407-3415 (C side) and rf_util.py:35-52 (ctypes mirror).
+ * Natural alignment, sizeof == 80.  Non-owning views on caller (NumPy) buffers.
+ *   dense : only `val` (rows*cols elements, row- or column-major per `type`)
+ *   sparse: CSR = (row_ptr[rows+1], col_idx[nnz], val_t[nnz]);
+ *           CSC = (col_ptr[cols+1], row_idx[nnz], val[nnz]); both always present.        */
+typedef struct {
+    uint64_t rows, cols, nnz;
+    size_t *row_ptr;
+    size_t *col_ptr;
+    uint32_t *row_idx;
+    uint32_t *col_idx;
+    void *val;
+    void *val_t;
+    int32_t type;
+} PyMatrix;
+
+/* c_trmf_train: reference trmf.h:203-210, trmf.cpp:696-725; ctypes prototype trmf.py:23-43.
+ *
+ *   Y        T x n observations (rows = timestamps). SPARSE required when missing != 0.
+ *   lag_set  ascending uint32[lag_size]
+ *   W        T x k DENSE_ROWMAJOR   (temporal factor, in/out)
+ *   H        n x k DENSE_ROWMAJOR   (item factor, in/out)
+ *   lag_val  lag_size x k DENSE_COLMAJOR (AR weights Theta, in/out)
+ *
+ * One ALS iteration = H(F)-solve, W(X)-solve, Theta-solve every period_Lag iterations
+ * (trmf.cpp:647-693).  Outputs are written in place; Y and lag_set are never written.
+ * Dimension/layout violations print the reference's "[ERR MSG]" lines on stderr and return
+ * without touching the outputs (trmf.cpp:561-596,632-634).  warm_start == 0 reproduces the
+ * reference's observable behaviour: the caller's arrays are not
+ * updated.  `threads` is accepted and ignored (no OpenMP on the device path).
+ * verbose >= 1 prints the reference's parameter dump on stdout and the per-half-step
+ * ">> iter i F|X|LV v" lines on stderr; verbose >= 2 adds the TRON line on stdout.          */
+TRMF_API void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_size,
+                  PyMatrix *pyW, PyMatrix *pyH, PyMatrix *pylag_val, int warm_start,
+                  double lambdaI, double lambdaAR, double lambdaLag,
+                  int32_t max_iter, int32_t period_W, int32_t period_H, int32_t period_Lag,
+                  int32_t threads, int32_t missing, int32_t verbose);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section 2 -- build-owned additions (no reference counterpart)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* sizeof(element type) of this library: 4 or 8. */
+TRMF_API int32_t trmf_sizeof_real(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). */
+TRMF_API int32_t trmf_device_count(void);
+/* Select the HIP device used by subsequent calls from this process (default 0). 0 on success. */
+TRMF_API int32_t trmf_set_device(int32_t device);
+/* Last error text of section-2 calls (static storage, never NULL). */
+TRMF_API const char *trmf_last_error(void);
+
+/* Per-iteration record filled by a session (mirrors the reference's verbose output:
+ * trmf.cpp:661,672,687 and the TRON line rf_tron.h:219). Values are -1 when a phase did not run. */
+typedef struct {
+    double normF, normX, normLV;           /* ||H||^2, ||W||^2, ||Theta||^2 after each phase   */
+    double f, fnew, actred, prered;        /* X-subproblem objective before/after, reductions  */
+    double gnorm, cg_rnorm;
+    int32_t cg_iter, accepted;
+    float ms_F, ms_X, ms_LV;               /* HIP-event time of each phase on the solver stream */
+    float ms_F_kernel;                     /* HIP-event time of the F-solve kernel alone       */
+} TrmfIterStats;
+
+typedef struct TrmfSession TrmfSession;
+
+/* Upload Y (both orientations), lag_set and the initial factors to HBM and build all device
+ * scratch.  Same argument meaning and validation as c_trmf_train.  Returns NULL on failure
+ * (see trmf_last_error()).  When a communicator is active (trmf_dist_init*), every rank must
+ * call this with identical inputs; rows are partitioned inside.                               */
+TRMF_API TrmfSession *trmf_session_create(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
+                                 const PyMatrix *W, const PyMatrix *H, const PyMatrix *lag_val,
+                                 double lambdaI, double lambdaAR, double lambdaLag,
+                                 int32_t period_W, int32_t period_H, int32_t period_Lag,
+                                 int32_t missing, int32_t verbose);
+/* Enqueue `iters` further ALS iterations (iteration numbering continues across calls, so the
+ * period_* gating matches one long c_trmf_train run).  Asynchronous unless verbose > 0.        */
+TRMF_API int32_t trmf_session_run(TrmfSession *s, int32_t iters);
+/* Block until all enqueued work of the session has finished. */
+TRMF_API int32_t trmf_session_sync(TrmfSession *s);
+/* Copy the current factors back into caller PyMatrix views (same shapes as at create). */
+TRMF_API int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val);
+/* Copy the stats of the last min(cap, iterations-run) iterations, oldest first. Returns count. */
+TRMF_API int32_t trmf_session_stats(TrmfSession *s, TrmfIterStats *out, int32_t cap);
+/* Global objective J of the current factors, evaluated on device in fp64. */
+TRMF_API double trmf_session_objective(TrmfSession *s);
+/* Algorithmic bytes of ONE F-solve launch on this rank: nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s
+ * over the item rows this rank owns. */
+TRMF_API double trmf_session_fsolve_bytes(TrmfSession *s);
+TRMF_API void trmf_session_destroy(TrmfSession *s);
+
+/* --- multi-GPU (one process per GPU; RCCL all-gathers over xGMI) ---------------------------- */
+#define TRMF_UNIQUE_ID_BYTES 128
+/* Rank 0: create an RCCL unique id; the caller broadcasts the bytes to all ranks
+ * (e.g. with torch.distributed) and every rank passes them to trmf_dist_init. */
+TRMF_API int32_t trmf_dist_get_unique_id(void *out_id /* TRMF_UNIQUE_ID_BYTES */);
+TRMF_API int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id /* TRMF_UNIQUE_ID_BYTES */);
+/* Host-staged communicator for tests and RCCL-less setups: `allgatherv` must gather, in place,
+ * the byte ranges [offsets[r], offsets[r+1]) of `buf` owned by each rank r. Returns 0 on success. */
+typedef int32_t (*trmf_allgatherv_fn)(void *buf, const uint64_t *offsets, int32_t world,
+                                      void *ctx);
+TRMF_API int32_t trmf_dist_init_callback(int32_t rank, int32_t world, trmf_allgatherv_fn allgatherv,
+                                void *ctx);
+TRMF_API int32_t trmf_dist_rank(void);
+TRMF_API int32_t trmf_dist_world(void);
+TRMF_API void trmf_dist_finalize(void);
+/* Contiguous row partition balanced by nnz: bounds[0]=0 <= ... <= bounds[world]=nrows. */
+TRMF_API int32_t trmf_partition_by_nnz(uint64_t nrows, const size_t *ptr, int32_t world,
+                              uint64_t *bounds /* world+1 */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRMF_ABI_H */

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Runs only in the build container: needs oracle/_ref/ (built by `make -C oracle ref` from the
+reference sources where they lie under /root/reference).  The reference ships no tests or golden
+vectors of its own, so every fixture here is captured from its c_trmf_train:
+inputs (sparse Y, lag_set, initial W/H/Theta, hyper-parameters) and outputs (final W/H/Theta, the
+per-half-step norms it prints on stderr at verbose>=1, and the CG step count / objective of the TRON
+line it prints on stdout at verbose>=2).
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+"""
+import os
+import re
+import sys
+import tempfile
+
+import numpy as np
+import scipy.sparse as smat
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, 'exp-trmf-nips16_amd'))
+sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+import oracle_py as O          # noqa: E402
+from trmf import synth         # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+class capture_fds(object):
+    """Capture what C code writes to fd 1 and fd 2."""
+
+    def __enter__(self):
+        sys.stdout.flush(); sys.stderr.flush()
+        self.saved = [os.dup(1), os.dup(2)]
+        self.tmp = [tempfile.TemporaryFile(), tempfile.TemporaryFile()]
+        os.dup2(self.tmp[0].fileno(), 1); os.dup2(self.tmp[1].fileno(), 2)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved[0], 1); os.dup2(self.saved[1], 2)
+        self.out, self.err = [], []
+        for t, dst in zip(self.tmp, (self.out, self.err)):
+            t.seek(0); dst.extend(t.read().decode().splitlines()); t.close()
+        for fd in self.saved:
+            os.close(fd)
+
+
+def run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
+    W, H, Th = W0.copy(), H0.copy(), np.asfortranarray(Th0.copy())
+    with capture_fds() as cap:
+        O.train_ref(Y, lag_set, W, H, Th, hyper, max_iter=max_iter, periods=periods, threads=4, missing=True, verbose=2)
+    normF = np.full(max_iter, -1.0); normX = np.full(max_iter, -1.0); normLV = np.full(max_iter, -1.0)
+    for line in cap.err:
+        m = re.match(r'>> iter (\d+) (F|X|LV) (\S+)$', line.strip())
+        if m:
+            {'F': normF, 'X': normX, 'LV': normLV}[m.group(2)][int(m.group(1)) - 1] = float(m.group(3))
+    cg, fx = [], []
+    for line in cap.out:
+        m = re.match(r'iter\s+\d+ act \S+ pre \S+ delta \S+ f (\S+) \|g\| \S+ CG\s+(\d+)', line.strip())
+        if m:
+            fx.append(float(m.group(1))); cg.append(int(m.group(2)))
+    return W, H, Th, normF, normX, normLV, np.array(cg, dtype=np.int32), np.array(fx)
+
+
+def make_case(name, n, T, k, lag_set, density, dtype, max_iter, seed=0, hyper=None, drop_rows=(), drop_cols=()):
+    hyper = dict(hyper or synth.HYPER)
+    prob = synth.sparse_problem(n, T, k, 3, density, dtype=dtype, seed=seed)   # nlag only shapes the data
+    Y = prob['Y'].tolil()
+    for r in drop_rows:
+        Y[r, :] = 0
+    for c in drop_cols:
+        Y[:, c] = 0
+    Y = smat.csr_matrix(Y); Y.eliminate_zeros(); Y.sort_indices()
+    lag_set = np.array(sorted(lag_set), dtype=np.uint32)
+    model = synth.initial_model(Y, lag_set, k, seed=seed)
+    W0, H0, Th0 = model.W.copy(), model.H.copy(), np.asfortranarray(model.lag_val.copy())
+    W, H, Th, nF, nX, nLV, cg, fx = run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter)
+    J = O.objective(Y, lag_set, W, H, Th, hyper)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(
+        path, Y_indptr=Y.indptr.astype(np.int64), Y_indices=Y.indices.astype(np.int32), Y_data=Y.data,
+        shape=np.array([T, n]), lag_set=lag_set, W0=W0, H0=H0, Th0=Th0, W=W, H=H, Th=Th,
+        normF=nF, normX=nX, normLV=nLV, cg_iter=cg, f_x=fx, objective=np.array(J),
+        lambdaI=hyper['lambdaI'], lambdaAR=hyper['lambdaAR'], lambdaLag=hyper['lambdaLag'],
+        max_iter=np.array(max_iter))
+    print('{:>14s}: T={} n={} k={} nnz={} {} iters={} cg={} J={:.6g} ({} KB)'.format(
+        name, T, n, k, Y.nnz, np.dtype(dtype).name, max_iter, cg.tolist(), J, os.path.getsize(path) // 1024))
+
+
+def main():
+    if O.ref(np.float32) is None:
+        sys.exit('oracle/_ref is missing: run `make -C oracle ref` first (build container only)')
+    make_case('tiny_f32', n=300, T=200, k=8, lag_set=[1, 2, 3], density=0.05, dtype=np.float32, max_iter=6)
+    make_case('tiny_f64', n=300, T=200, k=8, lag_set=[1, 2, 3], density=0.05, dtype=np.float64, max_iter=6)
+    # ragged: empty timestamps and empty items; lag 0 in the lag set (legal, trmf.py:354); k not a multiple of 8
+    make_case('ragged_f64', n=120, T=150, k=5, lag_set=[0, 1, 7], density=0.08, dtype=np.float64, max_iter=4,
+              drop_rows=(0, 17, 149), drop_cols=(3, 64, 119), seed=3)
+    make_case('k16_f32', n=400, T=250, k=16, lag_set=list(range(1, 9)), density=0.06, dtype=np.float32, max_iter=4, seed=1)
+    make_case('k40_f32', n=500, T=300, k=40, lag_set=list(range(1, 17)), density=0.2, dtype=np.float32, max_iter=4, seed=2)
+    make_case('k64_f64', n=260, T=220, k=64, lag_set=[1, 2, 4, 8, 16, 32], density=0.45, dtype=np.float64, max_iter=3, seed=4)
+    make_case('one_iter_f64', n=300, T=200, k=24, lag_set=[1, 2, 24], density=0.15, dtype=np.float64, max_iter=1, seed=5)
+
+
+if __name__ == '__main__':
+    main()

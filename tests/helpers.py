@@ -1,0 +1,50 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import glob
+import os
+
+import numpy as np
+import scipy.sparse as smat
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def golden_names():
+    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    T, n = [int(v) for v in z['shape']]
+    Y = smat.csr_matrix((z['Y_data'], z['Y_indices'], z['Y_indptr']), shape=(T, n))
+    g = {k: z[k] for k in z.files}
+    g['Y'] = Y
+    g['hyper'] = dict(lambdaI=float(z['lambdaI']), lambdaAR=float(z['lambdaAR']), lambdaLag=float(z['lambdaLag']))
+    g['max_iter'] = int(z['max_iter'])
+    g['dtype'] = z['W0'].dtype
+    return g
+
+
+def relmax(a, ref):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(ref, dtype=np.float64)).max()
+                 / max(np.abs(ref).max(), 1e-300))
+
+
+def relfro(a, ref):
+    a = np.asarray(a, dtype=np.float64); ref = np.asarray(ref, dtype=np.float64)
+    return float(np.linalg.norm(a - ref) / max(np.linalg.norm(ref), 1e-300))
+
+
+def make_model(W0, H0, Th0, lag_set):
+    """A trmf.Model over copies of the given initial factors."""
+    from trmf import Model
+    from trmf.rf_util import PyMatrix
+    dt = W0.dtype
+    return Model(pyW=PyMatrix(np.ascontiguousarray(W0.copy()), dt), pyH=PyMatrix(np.ascontiguousarray(H0.copy()), dt),
+                 pylag_val=PyMatrix(np.asfortranarray(Th0.copy()), dt), lag_set=np.array(lag_set, dtype=np.uint32))
+
+
+# parity tolerances (SURVEY.md 8(d) "Parity gates"), by element type
+TOL = {
+    'float64': dict(factor=1e-6, objective=1e-8),
+    'float32': dict(factor=1e-3, objective=1e-5),
+}

@@ -1,0 +1,130 @@
+"""CPU: the C-ABI libraries load, export every symbol include/trmf_abi.h declares, agree with the
+reference's PyMatrix layout, validate arguments like the reference, and fail LOUDLY (no silent CPU
+fallback) when no GPU is present.  No compute is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+from helpers import make_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, 'include', 'trmf_abi.h')
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    # declarations look like:  TRMF_API <return type> name(args);   (the #define line is skipped)
+    return sorted(set(re.findall(r'^TRMF_API\s[^;(]*?\b(\w+)\s*\(', text, flags=re.M)))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_library_exports_every_declared_symbol(dtype):
+    from trmf import session
+    lib = session.lib_for(dtype)
+    names = declared_symbols()
+    assert 'c_trmf_train' in names and len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), name
+    assert lib.trmf_sizeof_real() == np.dtype(dtype).itemsize
+
+
+def test_library_names_follow_reference_glob():
+    # reference loader: glob(<pkg>/corelib/trmf_float32*.so) (trmf.py:21-22, rf_util.py:23)
+    import glob
+    from trmf._corelib import corelib_path
+    assert glob.glob(os.path.join(corelib_path, 'trmf_float32*.so'))
+    assert glob.glob(os.path.join(corelib_path, 'trmf_float64*.so'))
+
+
+def test_pymatrix_layout_matches_reference_struct():
+    from trmf.rf_util import PyMatrix
+    # rf_matrix.h:3407-3415 with natural alignment
+    assert ctypes.sizeof(PyMatrix) == 80
+    expect = dict(rows=0, cols=8, nnz=16, row_ptr=24, col_ptr=32, row_idx=40, col_idx=48, val=56, val_t=64, type=72)
+    for name, off in expect.items():
+        assert getattr(PyMatrix, name).offset == off, name
+
+
+def test_pymatrix_conversions():
+    from trmf.rf_util import PyMatrix
+    rng = np.random.RandomState(0)
+    A = smat.random(7, 5, density=0.4, random_state=rng, format='csr', dtype=np.float64)
+    for fmt in (A, A.tocsc(), A.tocoo()):
+        m = PyMatrix(fmt, dtype=np.float32)
+        assert m.type == PyMatrix.SPARSE and m.nnz == A.nnz and (m.rows, m.cols) == (7, 5)
+        assert m.py_buf['row_ptr'].dtype == np.uint64 and m.py_buf['col_idx'].dtype == np.uint32
+        assert m.py_buf['val'].dtype == np.float32 and m.py_buf['val_t'].dtype == np.float32
+        csr = smat.csr_matrix((m.py_buf['val_t'], m.py_buf['col_idx'], m.py_buf['row_ptr'].astype(np.int64)), shape=(7, 5))
+        csc = smat.csc_matrix((m.py_buf['val'], m.py_buf['row_idx'], m.py_buf['col_ptr'].astype(np.int64)), shape=(7, 5))
+        assert np.allclose(csr.toarray(), A.toarray()) and np.allclose(csc.toarray(), A.toarray())
+    C = np.zeros((4, 3), order='C'); F = np.zeros((4, 3), order='F')
+    assert PyMatrix(C, np.float64).type == PyMatrix.DENSE_ROWMAJOR
+    assert PyMatrix(F, np.float64).type == PyMatrix.DENSE_COLMAJOR
+    assert PyMatrix(np.zeros((4, 1)), np.float64).type == PyMatrix.DENSE_COLMAJOR     # quirk Q2
+
+
+def test_partition_by_nnz():
+    from trmf.session import partition_by_nnz
+    rng = np.random.RandomState(1)
+    counts = rng.poisson(20, size=1000)
+    counts[100:140] = 0
+    ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.uint64)
+    for world in (1, 2, 3, 8):
+        b = partition_by_nnz(ptr, world)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b.astype(np.int64)) >= 0)
+        loads = [int(ptr[b[r + 1]] - ptr[b[r]]) for r in range(world)]
+        assert max(loads) - min(loads) <= 2 * counts.max()
+    # all-empty matrix: even row split
+    b = partition_by_nnz(np.zeros(11, dtype=np.uint64), 4)
+    assert b.tolist() == [0, 2, 5, 7, 10]
+
+
+def _tiny():
+    rng = np.random.RandomState(0)
+    Y = smat.random(30, 20, density=0.3, random_state=rng, format='csr', dtype=np.float32)
+    W0 = rng.rand(30, 4).astype(np.float32); H0 = rng.rand(20, 4).astype(np.float32)
+    Th0 = np.asfortranarray(rng.randn(2, 4).astype(np.float32))
+    return Y, W0, H0, Th0
+
+
+def test_dimension_errors_leave_outputs_untouched(capfd):
+    import trmf
+    Y, W0, H0, Th0 = _tiny()
+    model = make_model(W0[:-1], H0, Th0, [1, 2])                 # W has the wrong row count
+    trmf.train(Y, model, missing=True, max_iter=2)
+    err = capfd.readouterr().err
+    assert '[ERR MSG]: Y.rows (30) != W.rows (29)' in err         # trmf.cpp:563-566
+    assert np.array_equal(model.W, W0[:-1]) and np.array_equal(model.H, H0)
+
+
+def test_cold_start_is_a_noop_like_the_reference():
+    # warm_start=0 never updates the caller's arrays
+    from trmf import session
+    from trmf.rf_util import PyMatrix
+    from ctypes import POINTER, byref, c_uint32
+    Y, W0, H0, Th0 = _tiny()
+    model = make_model(W0, H0, Th0, [1, 2])
+    lib = session.lib_for(np.float32)
+    pyY = PyMatrix(Y, np.float32)
+    lib.c_trmf_train(byref(pyY), model.lag_set.ctypes.data_as(POINTER(c_uint32)), 2, byref(model.pyW),
+                     byref(model.pyH), byref(model.pylag_val), 0, 0.5, 50.0, 0.5, 2, 1, 1, 2, 1, 1, 0)
+    assert np.array_equal(model.W, W0) and np.array_equal(model.H, H0) and np.array_equal(model.lag_val, Th0)
+
+
+def test_no_gpu_means_loud_failure_not_cpu_fallback(capfd, have_gpu):
+    if have_gpu:
+        pytest.skip('a GPU is present')
+    import trmf
+    from trmf import session
+    Y, W0, H0, Th0 = _tiny()
+    model = make_model(W0, H0, Th0, [1, 2])
+    trmf.train(Y, model, missing=True, max_iter=2, lambdaI=0.5, lambdaAR=50, lambdaLag=0.5)
+    err = capfd.readouterr().err
+    assert 'no HIP device' in err
+    assert np.array_equal(model.W, W0) and np.array_equal(model.H, H0)      # nothing computed on the host
+    with pytest.raises(RuntimeError, match='no HIP device'):
+        session.Session(Y, model, missing=True)
