@@ -1,0 +1,180 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (1) the golden vectors captured from
+the real reference, (2) the C restatement on fresh seeded inputs, (3) size-independent properties at
+BASELINE.json's full sizes.  Tolerances are SURVEY.md 8(d)'s parity gates (see helpers.TOL)."""
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+import oracle_py as O
+import trmf
+from helpers import TOL, golden_names, load_golden, make_model, relfro, relmax
+from trmf import session, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_product(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
+    model = make_model(W0, H0, Th0, lag_set)
+    trmf.train(Y, model, max_iter=max_iter, period_W=periods[0], period_H=periods[1], period_Lag=periods[2],
+               missing=True, **hyper)
+    return model
+
+
+def test_device_is_visible():
+    assert session.lib_for(np.float32).trmf_device_count() >= 1
+    assert session.lib_for(np.float64).trmf_device_count() >= 1
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_one_fsolve_matches_golden_inputs(name):
+    """One F-solve only (period_W, period_Lag > max_iter) vs the restatement: direct solve, tight gate."""
+    g = load_golden(name)
+    big = 10 ** 6
+    m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], 1, periods=(big, 1, big))
+    W, H, Th = g['W0'].copy(), g['H0'].copy(), np.asfortranarray(g['Th0'].copy())
+    O.train_port(g['Y'], g['lag_set'], W, H, Th, g['hyper'], max_iter=1, periods=(big, 1, big))
+    tol = 1e-6 if g['dtype'] == np.float64 else 2e-4          # fp64 gate: max|d|/max|ref| <= 1e-6
+    assert relmax(m.H, H) < tol
+    assert np.array_equal(m.W, g['W0']) and np.array_equal(m.lag_val, g['Th0'])     # untouched phases
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_full_run_matches_golden(name):
+    g = load_golden(name)
+    m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], g['max_iter'])
+    tol = TOL[np.dtype(g['dtype']).name]
+    assert relfro(m.W, g['W']) < tol['factor']
+    assert relfro(m.H, g['H']) < tol['factor']
+    assert relfro(m.lag_val, g['Th']) < tol['factor'] * 10
+    J = O.objective(g['Y'], g['lag_set'], m.W, m.H, m.lag_val, g['hyper'])
+    assert abs(J - float(g['objective'])) / float(g['objective']) < tol['objective']
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_session_log_matches_reference_observables(name):
+    """Norms the reference prints (trmf.cpp:661,672,687) and its CG step counts (rf_tron.h:219)."""
+    g = load_golden(name)
+    model = make_model(g['W0'], g['H0'], g['Th0'], g['lag_set'])
+    with session.Session(g['Y'], model, missing=True, **g['hyper']) as s:
+        s.run(g['max_iter'])
+        st = s.stats(g['max_iter'])
+        Jdev = s.objective()
+        s.download()
+    assert len(st) == g['max_iter']
+    rtol = 2e-5 if g['dtype'] == np.float64 else 2e-4
+    for key in ('normF', 'normX', 'normLV'):
+        ref = g[key]; got = np.array([x[key] for x in st])
+        assert np.allclose(got[ref >= 0], ref[ref >= 0], rtol=rtol), key
+        assert np.all(got[ref < 0] == -1), key
+    cg = np.array([x['cg_iter'] for x in st])
+    assert np.all(np.abs(cg - g['cg_iter']) <= 1)                # gate: equal +-1 (truncated CG)
+    if g['dtype'] == np.float64:
+        assert cg.tolist() == g['cg_iter'].tolist()
+    assert all(x['accepted'] == 1 for x in st)
+    assert np.allclose([x['f'] for x in st], g['f_x'], rtol=2e-3)   # %5.3e in the TRON line
+    J = O.objective(g['Y'], g['lag_set'], model.W, model.H, model.lag_val, g['hyper'])
+    assert abs(Jdev - J) / J < 1e-5
+
+
+@pytest.mark.parametrize('dtype,k,nlag', [(np.float32, 16, 8), (np.float32, 40, 16), (np.float64, 24, 4),
+                                          (np.float64, 60, 5), (np.float32, 3, 2), (np.float32, 64, 32)])
+def test_fresh_seeded_problem_vs_restatement(dtype, k, nlag):
+    """4 ALS iterations vs the restatement.  Gate: SURVEY.md 8(d) tolerances.  A truncated fp32 CG on
+    an ill-conditioned system amplifies last-bit differences (the reference's own fp32 build has the
+    same noise floor), so an fp32 case may alternatively show that it is no farther from the fp64
+    trajectory than the fp32 restatement itself is (factor 3)."""
+    p = synth.sparse_problem(n=1500, T=max(700, 3 * nlag), k=k, nlag=nlag, density=0.05, dtype=dtype, seed=7)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], k, seed=7)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    iters = 4
+    O.train_port(p['Y'], p['lag_set'], W, H, Th, synth.HYPER, max_iter=iters)
+    m = run_product(p['Y'], p['lag_set'], m0.W, m0.H, m0.lag_val, synth.HYPER, iters)
+    tol = TOL[np.dtype(dtype).name]
+    Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
+    Jp = O.objective(p['Y'], p['lag_set'], m.W, m.H, m.lag_val, synth.HYPER)
+    direct = (relfro(m.W, W) < tol['factor'] and relfro(m.H, H) < tol['factor']
+              and relfro(m.lag_val, Th) < tol['factor'] * 10 and abs(Jp - Jo) / Jo < tol['objective'])
+    if direct or dtype == np.float64:
+        assert direct
+        return
+    Y64 = p['Y'].astype(np.float64)
+    W64, H64 = m0.W.astype(np.float64), m0.H.astype(np.float64)
+    T64 = np.asfortranarray(m0.lag_val.astype(np.float64))
+    O.train_port(Y64, p['lag_set'], W64, H64, T64, synth.HYPER, max_iter=iters)
+    J64 = O.objective(Y64, p['lag_set'], W64, H64, T64, synth.HYPER)
+    print('fp32 noise floor: |port32-f64| W %.2e H %.2e J %.2e ; |gpu32-f64| W %.2e H %.2e J %.2e' % (
+        relfro(W, W64), relfro(H, H64), abs(Jo - J64) / J64, relfro(m.W, W64), relfro(m.H, H64), abs(Jp - J64) / J64))
+    assert relfro(m.W, W64) < 3 * relfro(W, W64) + tol['factor']
+    assert relfro(m.H, H64) < 3 * relfro(H, H64) + tol['factor']
+    assert abs(Jp - J64) / J64 < 3 * abs(Jo - J64) / J64 + tol['objective']
+
+
+def test_objective_parity_fp32_10_iterations_config2_shape():
+    """north_star gate: fp32 objective within 1e-5 relative after 10 ALS iterations (config-2 shape)."""
+    cfg = synth.CONFIGS['c2']
+    p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float32, seed=0)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], cfg['k'], seed=0)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    log = O.train_port(p['Y'], p['lag_set'], W, H, Th, synth.HYPER, max_iter=10, threads=8)
+    model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+    with session.Session(p['Y'], model, missing=True, **synth.HYPER) as s:
+        s.run(10); st = s.stats(10); s.download()
+    Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
+    Jp = O.objective(p['Y'], p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
+    print('cg oracle', [l['cg_iter'] for l in log], 'cg gpu', [x['cg_iter'] for x in st], 'J', Jo, Jp)
+    assert abs(Jp - Jo) / Jo < 1e-5
+    assert relfro(model.W, W) < 1e-3 and relfro(model.H, H) < 1e-3
+
+
+def test_empty_rows_and_columns_are_left_untouched():
+    rng = np.random.RandomState(5)
+    Y = smat.random(120, 90, density=0.1, random_state=rng, format='lil', dtype=np.float64)
+    Y[10, :] = 0; Y[:, 33] = 0; Y[:, 89] = 0
+    Y = smat.csr_matrix(Y); Y.eliminate_zeros()
+    m0 = synth.initial_model(Y, [1, 2], 7, seed=1)
+    big = 10 ** 6
+    m = run_product(Y, m0.lag_set, m0.W, m0.H, m0.lag_val, synth.HYPER, 1, periods=(big, 1, big))
+    assert np.array_equal(m.H[33], m0.H[33]) and np.array_equal(m.H[89], m0.H[89])    # trmf.cpp:374
+    assert not np.array_equal(m.H[0], m0.H[0])
+
+
+def test_unsupported_inputs_fail_loudly(capfd):
+    rng = np.random.RandomState(0)
+    Yd = rng.rand(30, 20).astype(np.float32)
+    m0 = synth.initial_model(smat.csr_matrix(Yd), [1, 2], 4, seed=0)
+    W0 = m0.W.copy()
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    trmf.train(Yd, model, missing=False, max_iter=1)
+    assert 'missing=0' in capfd.readouterr().err and np.array_equal(model.W, W0)
+
+
+def test_full_size_headline_properties():
+    """Config 3 (100k x 10k, 1%, k=40, |L|=16, fp32): size-independent properties of the solver --
+    every F row satisfies its normal equations, every accepted CG step reduces the X objective by the
+    predicted amount, and the global objective decreases monotonically."""
+    cfg = synth.CONFIGS['c3']
+    p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float32, seed=0)
+    Y = p['Y']
+    m0 = synth.initial_model(Y, p['lag_set'], cfg['k'], seed=0)
+    model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+    J = [O.objective(Y, p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)]
+    with session.Session(Y, model, missing=True, **synth.HYPER) as s:
+        assert abs(s.fsolve_bytes() - (Y.nnz * (4 + 4 + 40 * 4) + (cfg['n'] + 1) * 8 + cfg['n'] * 40 * 4)) < 1
+        for it in range(3):
+            Wprev = model.W.copy()
+            s.run(1); st = s.stats(1)[0]; s.download()
+            J.append(O.objective(Y, p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER))
+            # normal-equation residual of a sample of F rows against the W used by that F-solve
+            Yc = Y.tocsc()
+            rows = np.random.RandomState(it).choice(cfg['n'], 200, replace=False)
+            for i in rows:
+                tt = Yc.indices[Yc.indptr[i]:Yc.indptr[i + 1]]
+                if len(tt) == 0:
+                    continue
+                P = Wprev[tt].astype(np.float64); y = Yc.data[Yc.indptr[i]:Yc.indptr[i + 1]].astype(np.float64)
+                A = P.T @ P + synth.HYPER['lambdaI'] * np.eye(40); b = P.T @ y
+                h = model.H[i].astype(np.float64)
+                assert np.linalg.norm(A @ h - b) <= 2e-4 * (np.linalg.norm(A) * np.linalg.norm(h) + np.linalg.norm(b))
+            assert st['accepted'] == 1 and 1 <= st['cg_iter'] <= 20
+            assert abs(st['actred'] - st['prered']) <= 2e-3 * abs(st['prered']) + 1e-3 * abs(st['f'])   # quadratic model
+    assert all(J[i + 1] < J[i] for i in range(len(J) - 1)), J
