@@ -19,6 +19,9 @@
 //   loss_kernel     sum of squared residuals per timestamp row (trmf.cpp:231-245, loss part).
 #pragma once
 
+#include <type_traits>
+#include <utility>
+
 #include "common.hpp"
 
 namespace trmf {
@@ -247,6 +250,176 @@ __global__ __launch_bounds__(256) void fsolve_kernel(const uint32_t *__restrict_
     }
     if (lane < k) F[(size_t)row * KP + lane] = x;
 }
+
+#if defined(TRMF_F32)
+// ---- F-solve, quad form (fp32): one wavefront per FOUR item rows ------------------------------------
+// The O(k^3) part of the solve is a chain of rank-1 updates whose operands must be broadcast across
+// lanes.  With one system per wavefront (fsolve_kernel above) every broadcast is a v_readlane that
+// feeds a single FMA per lane, and the kernel is VALU-issue bound (~3000 of its ~3500 instructions).
+// Here the four 16-lane rows of a wavefront each own one system: lane (grp, c) holds columns
+// {c, 16+c, 32+c, ...} of system `grp`, one ds_swizzle row-broadcast serves all four systems and
+// feeds up to NT FMAs per lane, and the back substitution reduces inside the 16-lane row with DPP.
+// The four Grams are still accumulated one after the other with the full-wave MFMA of gram_row().
+template <int... Is, typename Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// value of lane SRC (0..15) of the caller's own 16-lane row (ds_swizzle bit mode, no LDS memory)
+template <int SRC> __device__ __forceinline__ float row_bcast(float v) {
+    constexpr int pattern = (SRC << 5) | 0x10;          // and_mask = 0x10, or_mask = SRC, xor_mask = 0
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), pattern));
+}
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_allsum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    return v;
+}
+
+template <int NT, int KMAX>
+__global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
+                                                          const uint32_t *__restrict__ idx,
+                                                          const float *__restrict__ val,
+                                                          const float *__restrict__ X,
+                                                          float *__restrict__ F, uint32_t row_begin,
+                                                          uint32_t row_end, int k, float lambda) {
+    static_assert(sizeof(real) == 4, "quad F-solve is the fp32 path");
+    constexpr int KP = kTile * NT, LDC = KP + 4;        // column-major slab: S[col * LDC + row]
+    __shared__ __attribute__((aligned(16))) float lds[4][KP * LDC];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, c = lane & 15;
+    const uint32_t row0 = row_begin + (blockIdx.x * 4u + (uint32_t)wave) * 4u;
+    if (row0 >= row_end) return;                        // wave-uniform; no block barrier below
+    float *S = lds[wave];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+
+    // areg[q][s] = A[s][16q + c] of this lane row's system; only s <= 16q+15 is ever touched
+    float areg[NT][KMAX];
+    float bz[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+        bz[q] = 0;
+#pragma unroll
+        for (int s = 0; s < KMAX; s++) areg[q][s] = (s == kTile * q + c) ? 1.0f : 0.0f;   // idle rows: identity
+    }
+    bool mine = false;
+
+#pragma unroll
+    for (int sys = 0; sys < 4; sys++) {
+        const uint32_t row = row0 + (uint32_t)sys;
+        uint32_t p0 = 0, p1 = 0;
+        if (row < row_end) { p0 = ptr[row]; p1 = ptr[row + 1]; }
+        if (p0 == p1) continue;                         // trmf.cpp:374 (wave-uniform)
+        GramState<NT> st;
+#pragma unroll
+        for (int t = 0; t < NT * (NT + 1) / 2; t++) st.acc[t] = typename Mfma16<real>::acc_t{0, 0, 0, 0};
+        real nowq[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) { st.b[q] = 0; nowq[q] = 0; }
+        st.loss = 0;
+        gram_row<NT, true, false>(st, idx, val, X, p0, p1, 0, 1, lane, nowq);
+#pragma unroll
+        for (int q = 0; q < NT; q++) {
+            st.b[q] += __shfl_xor(st.b[q], 16, kWave);
+            st.b[q] += __shfl_xor(st.b[q], 32, kWave);
+        }
+        // + lambda on the diagonal (trmf.cpp:393), then accumulators -> slab, 4 consecutive rows per store
+        {
+            int t = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+                for (int tj = ti; tj < NT; tj++, t++) {
+                    f4 v = st.acc[t];
+                    if (ti == tj) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++) if (c == 4 * grp + r) v[r] += lambda;
+                    }
+                    *reinterpret_cast<f4 *>(&S[(kTile * tj + c) * LDC + kTile * ti + 4 * grp]) = v;
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (grp == sys) {
+            mine = true;
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                bz[q] = st.b[q];
+                constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+                for (int s4 = 0; s4 < KMAX / 4; s4++) {
+                    if (4 * s4 <= kTile * q + 15) {
+                        const f4 v = *reinterpret_cast<const f4 *>(&S[(kTile * q + c) * LDC + 4 * s4]);
+                        areg[q][4 * s4 + 0] = v[0]; areg[q][4 * s4 + 1] = v[1];
+                        areg[q][4 * s4 + 2] = v[2]; areg[q][4 * s4 + 3] = v[3];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- four right-looking Cholesky factorisations side by side, forward substitution fused ----
+    float dinv[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) dinv[q] = 0;
+    static_for<KMAX>([&](auto J) {
+        constexpr int j = decltype(J)::value, qj = j >> 4, cj = j & 15;
+        if (j < k) {
+            const float inv = inv_sqrt(row_bcast<cj>(areg[qj][j]));
+            float u[NT];
+#pragma unroll
+            for (int q = qj; q < NT; q++) {
+                u[q] = areg[q][j] * inv;
+                if (q == qj && c <= cj) u[q] = 0;       // row j of U, strictly right of the diagonal
+                areg[q][j] = u[q];
+            }
+            const float zj = row_bcast<cj>(bz[qj]) * inv;
+#pragma unroll
+            for (int q = qj; q < NT; q++) bz[q] = fmaf(-u[q], zj, bz[q]);
+            if (c == cj) { bz[qj] = zj; dinv[qj] = inv; }
+            static_for<KMAX>([&](auto Sx) {
+                constexpr int s = decltype(Sx)::value, qs = s >> 4, cs = s & 15;
+                if constexpr (s > j) {
+                    const float us = row_bcast<cs>(u[qs]);
+#pragma unroll
+                    for (int q = qs; q < NT; q++) areg[q][s] = fmaf(-us, u[q], areg[q][s]);
+                }
+            });
+        }
+    });
+
+    // ---- back substitution U x = z, row-oriented, reduction inside the 16-lane row ----
+    float x[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) x[q] = 0;
+    static_for<KMAX>([&](auto Jr) {
+        constexpr int j = KMAX - 1 - decltype(Jr)::value, qj = j >> 4, cj = j & 15;
+        if (j < k) {
+            float part = 0;
+#pragma unroll
+            for (int q = qj; q < NT; q++) part = fmaf(areg[q][j], x[q], part);
+            const float sum = row16_allsum_dpp(part);
+            const float xv = (bz[qj] - sum) * dinv[qj];
+            if (c == cj) x[qj] = xv;
+        }
+    });
+    if (mine) {
+#pragma unroll
+        for (int q = 0; q < NT; q++)
+            if (kTile * q + c < k) F[(size_t)(row0 + grp) * KP + kTile * q + c] = x[q];
+    }
+}
+
+#endif  // TRMF_F32
 
 // ---- X-side Gram cache: one workgroup (4 waves) per timestamp row ---------------------------------
 template <int NT>

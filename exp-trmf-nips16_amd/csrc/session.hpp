@@ -118,6 +118,7 @@ struct TrmfSessionImpl {
         KP = padded_rank(k); NT = KP / kTile; KMAX = ((k + 7) / 8) * 8;
         nlag = (int)lag_size; midx = nlag ? (int)lags[nlag - 1] : 0;
         comm = active_comm();
+        if (const char *e = getenv("TRMF_FSOLVE")) use_quad = use_quad && std::string(e) != "wave";
         host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
@@ -177,9 +178,33 @@ struct TrmfSessionImpl {
                            Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI);
         return 0;
     }
+    template <int NT_, int KMAX_> int launch_fsolve_quad(uint32_t rb, uint32_t re) {
+        const uint32_t rows = re - rb;
+        if (rows == 0) return 0;
+#if defined(TRMF_F32)
+        hipLaunchKernelGGL((fsolve_quad_kernel<NT_, KMAX_>), dim3((rows + 15) / 16), dim3(256), 0, stream,
+                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI);
+#endif
+        return 0;
+    }
+    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64 or TRMF_FSOLVE=wave: one per wavefront
+    bool use_quad = sizeof(real) == 4;
     int fsolve(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        if (use_quad) {
+            switch (KMAX) {
+                case 8:  launch_fsolve_quad<1, 8>(rb, re); break;
+                case 16: launch_fsolve_quad<1, 16>(rb, re); break;
+                case 24: launch_fsolve_quad<2, 24>(rb, re); break;
+                case 32: launch_fsolve_quad<2, 32>(rb, re); break;
+                case 40: launch_fsolve_quad<3, 40>(rb, re); break;
+                case 48: launch_fsolve_quad<3, 48>(rb, re); break;
+                case 56: launch_fsolve_quad<4, 56>(rb, re); break;
+                case 64: launch_fsolve_quad<4, 64>(rb, re); break;
+                default: set_error("unsupported rank"); return kFail;
+            }
+        } else
         switch (KMAX) {
             case 8:  launch_fsolve<1, 8>(rb, re); break;
             case 16: launch_fsolve<1, 16>(rb, re); break;
