@@ -77,108 +77,162 @@ template <typename T> __device__ __forceinline__ T wave_allsum(T v) {
     return v;
 }
 
-// ---- Gram accumulation over one CSR row ----------------------------------------------------------
+template <int... Is, typename Fn>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+// ---- Gram accumulation: a software-pipelined ring over a stream of observed entries ------------------
+//
+// One "group" = 4 consecutive observed entries of one row = one K=4 slice of the MFMA.  Lane
+// (g = lane>>4, c = lane&15) loads entry e0 + u*estride + g and the factor slices X[j][16q + c].
+// An "iteration" = D groups.  The loop body is ONE basic block with statically indexed slots, so
+// the compiler's s_waitcnt vmcnt(N) are exact and the loads really stay in flight:
+//     entry (idx, val)   loaded TWO iterations ahead   (slots jA / yA)
+//     factor slices      loaded ONE iteration ahead    (slots x / yx)
+// Nothing is selected on a freshly loaded value (a `valid ? x : 0` right after the load costs the
+// full load latency every group -- measured); masked-out lanes instead point at an all-zero pad row
+// of X (`zero_row`) and get y = 0 when their slot is promoted one iteration later.
+// Streams are described per iteration by a wave-uniform GramDesc; rows are padded to a multiple of D
+// groups (<= D-1 all-zero groups per row).
+struct GramDesc {
+    uint32_t e0;      // first entry of the iteration's first group
+    uint32_t end;     // one past the row's last entry; end <= e0 means "no work" (all lanes masked)
+    int row;          // caller-defined tag (system index); < 0 terminates the stream
+};
+
+template <typename T> __device__ __forceinline__ T row16_sum(T v) { return row16_allsum(v); }
+#if defined(TRMF_F32)
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_allsum_dpp(float v) {
+    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);     // row_half_mirror
+    v += dpp_mov<0x140>(v);     // row_mirror
+    return v;
+}
+template <> __device__ __forceinline__ float row16_sum<float>(float v) { return row16_allsum_dpp(v); }
+#endif
+
 template <int NT> struct GramState {
     typename Mfma16<real>::acc_t acc[NT * (NT + 1) / 2];   // upper tiles, row-major over (ti<=tj)
     real b[NT];                                            // rhs partial of this lane group
     double loss;
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int t = 0; t < NT * (NT + 1) / 2; t++) acc[t] = typename Mfma16<real>::acc_t{0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < NT; q++) b[q] = 0;
+        loss = 0;
+    }
 };
 
-// Lane (g = lane>>4, c = lane&15) handles observed entry 4*group+g and factor columns 16q+c.
-// `wsub`/`nsub`: this wavefront takes groups wsub, wsub+nsub, ... of the row.
-template <int NT, bool DO_MMA, bool WITH_LOSS>
-__device__ __forceinline__ void gram_row(GramState<NT> &st, const uint32_t *__restrict__ idx,
-                                         const real *__restrict__ val, const real *__restrict__ X,
-                                         uint32_t p0, uint32_t p1, int wsub, int nsub, int lane,
-                                         const real (&wq)[NT]) {
+// next(desc): advance a wave-uniform descriptor to the following iteration of the stream.
+// row_done(row): called between iterations when the stream leaves `row` (st holds its Gram/rhs/loss).
+template <int NT, int D, bool DO_MMA, bool WITH_LOSS, typename Next, typename RowDone>
+__device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__restrict__ idx,
+                                          const real *__restrict__ val, const real *__restrict__ X,
+                                          uint32_t zero_row, uint32_t estride, int lane,
+                                          const real (&wq)[NT], GramDesc d0, Next &&next,
+                                          RowDone &&row_done) {
     constexpr int KP = kTile * NT;
-    const int g = lane >> 4, c = lane & 15;
-    const uint32_t step = 4u * (uint32_t)nsub;
-    uint32_t base = p0 + 4u * (uint32_t)wsub;
+    const uint32_t g = (uint32_t)(lane >> 4), c = (uint32_t)(lane & 15);
+    uint32_t jA[D]; real yA[D]; bool vA[D];
+    real x[D][NT], yx[D];
 
-    // software pipeline: indices two groups ahead, factor slices one group ahead
-    uint32_t j1 = 0; real y0 = 0, y1 = 0; bool v1 = false;
-    real x0[NT], x1[NT];
-    {
-        const uint32_t p = base + g;
-        const bool v = p < p1;
-        const uint32_t j = v ? idx[p] : 0u;
-        y0 = v ? val[p] : real(0);
+    auto load_entries = [&](const GramDesc &d, auto U) {
+        constexpr int u = decltype(U)::value;
+        const uint32_t p = d.e0 + (uint32_t)u * estride + g;
+        vA[u] = p < d.end;
+        const uint32_t pc = vA[u] ? p : 0u;              // clamped: never reads out of bounds
+        jA[u] = idx[pc];
+        yA[u] = val[pc];
+    };
+    auto load_slices = [&](auto U) {                     // promote slot u: entries -> factor slices
+        constexpr int u = decltype(U)::value;
+        const uint32_t j = vA[u] ? jA[u] : zero_row;
+        yx[u] = vA[u] ? yA[u] : real(0);
+        const real *src = X + (size_t)j * KP + c;
 #pragma unroll
-        for (int q = 0; q < NT; q++) {
-            const real x = X[(size_t)j * KP + kTile * q + c];
-            x0[q] = v ? x : real(0);
-        }
-        const uint32_t pn = base + step + g;
-        v1 = pn < p1;
-        j1 = v1 ? idx[pn] : 0u;
-        y1 = v1 ? val[pn] : real(0);
-    }
-    while (base < p1) {
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-            const real x = X[(size_t)j1 * KP + kTile * q + c];
-            x1[q] = v1 ? x : real(0);
-        }
-        const uint32_t p2 = base + 2u * step + g;
-        const bool v2 = p2 < p1;
-        const uint32_t j2 = v2 ? idx[p2] : 0u;
-        const real y2 = v2 ? val[p2] : real(0);
+        for (int q = 0; q < NT; q++) x[u][q] = src[kTile * q];
+    };
 
-        // ---- consume group 0 ----
+    GramDesc d1 = d0; next(d1);
+    GramDesc d2 = d1; next(d2);
+    static_for<D>([&](auto U) { load_entries(d0, U); });
+    static_for<D>([&](auto U) { load_slices(U); load_entries(d1, U); });
+    while (d0.row >= 0) {
+        // ---- single basic block: consume iteration d0, fetch slices of d1, entries of d2 ----
+        static_for<D>([&](auto U) {
+            constexpr int u = decltype(U)::value;
 #pragma unroll
-        for (int q = 0; q < NT; q++) st.b[q] = fma(y0, x0[q], st.b[q]);
-        if (DO_MMA) {
-            int t = 0;
+            for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
+            if (DO_MMA) {
+                int t = 0;
 #pragma unroll
-            for (int ti = 0; ti < NT; ti++)
+                for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-                for (int tj = ti; tj < NT; tj++, t++)
-                    st.acc[t] = Mfma16<real>::mma(x0[ti], x0[tj], st.acc[t]);
-        }
-        if (WITH_LOSS) {
-            real d = 0;
+                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(x[u][ti], x[u][tj], st.acc[t]);
+            }
+            if (WITH_LOSS) {
+                real d = 0;
 #pragma unroll
-            for (int q = 0; q < NT; q++) d = fma(wq[q], x0[q], d);
-            d = row16_allsum(d);
-            const real res = y0 - d;                      // trmf.cpp:238 (val_type arithmetic)
-            st.loss += (double)res * (double)res;         // invalid entries: y0 = x0 = 0 -> 0
-        }
-        // ---- rotate ----
-#pragma unroll
-        for (int q = 0; q < NT; q++) x0[q] = x1[q];
-        y0 = y1; j1 = j2; y1 = y2; v1 = v2;
-        base += step;
+                for (int q = 0; q < NT; q++) d = fma(wq[q], x[u][q], d);
+                d = row16_sum(d);
+                const real res = yx[u] - d;               // trmf.cpp:238 (val_type arithmetic)
+                st.loss += (double)res * (double)res;     // masked lanes: y = 0, x = 0 -> 0
+            }
+            load_slices(U);
+            load_entries(d2, U);
+        });
+        // ---- between iterations ----
+        if (d1.row != d0.row) { row_done(d0.row); }
+        d0 = d1; d1 = d2; next(d2);
     }
 }
 
-// ---- F-solve: one wavefront per item row -----------------------------------------------------------
+// Single-row stream: groups e0, e0+estride, ... of [p0, p1).
+struct SingleRowStream {
+    uint32_t step;    // entries per iteration = D * estride
+    __device__ __forceinline__ void operator()(GramDesc &d) const {
+        if (d.row < 0) return;
+        d.e0 += step;
+        if (d.e0 >= d.end) { d.row = -1; d.end = 0; }
+    }
+};
+
+// ---- F-solve: one wavefront per item row (any element type; the fp64 path) ---------------------------
 // KMAX: static bound of the factorisation loops, k <= KMAX <= 16*NT (KMAX = k rounded up to 8).
+constexpr int kRingDepth = 4;      // groups per iteration of gram_ring (rows padded to a multiple)
+
 template <int NT, int KMAX>
 __global__ __launch_bounds__(256) void fsolve_kernel(const uint32_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ idx,
                                                      const real *__restrict__ val,
                                                      const real *__restrict__ X,
                                                      real *__restrict__ F, uint32_t row_begin,
-                                                     uint32_t row_end, int k, real lambda) {
+                                                     uint32_t row_end, int k, real lambda,
+                                                     uint32_t zero_row) {
     constexpr int KP = kTile * NT, LD = KP + 1;
     __shared__ real lds[4][KP * LD];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
     if (row >= row_end) return;                         // wave-uniform; no block barrier below
-    const uint32_t p0 = ptr[row], p1 = ptr[row + 1];
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
     if (p0 == p1) return;                               // trmf.cpp:374: empty rows stay untouched
 
     GramState<NT> st;
-#pragma unroll
-    for (int t = 0; t < NT * (NT + 1) / 2; t++) st.acc[t] = typename Mfma16<real>::acc_t{0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < NT; q++) st.b[q] = 0;
-    st.loss = 0;
+    st.clear();
     real nowq[NT];
 #pragma unroll
     for (int q = 0; q < NT; q++) nowq[q] = 0;
-    gram_row<NT, true, false>(st, idx, val, X, p0, p1, 0, 1, lane, nowq);
+    gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
+                                           SingleRowStream{4u * kRingDepth}, [](int) {});
 
     const int g = lane >> 4, c = lane & 15;
     // rhs: fold the 4 lane groups; afterwards lane t owns b[t] = st.b[t>>4]
@@ -227,7 +281,7 @@ __global__ __launch_bounds__(256) void fsolve_kernel(const uint32_t *__restrict_
             const real zj = lane_bcast(bz, j) * inv;
             bz = fma(-u, zj, bz);
             if (lane == j) { bz = zj; dinv = inv; }
-            S[j * LD + col] = u;                                // row layout for the back solve
+            if (lane < KP) S[j * LD + col] = u;                 // row layout for the back solve
 #pragma unroll
             for (int s = j + 1; s < KMAX; s++) a[s] = fma(-lane_bcast(u, s), u, a[s]);
         }
@@ -259,45 +313,69 @@ __global__ __launch_bounds__(256) void fsolve_kernel(const uint32_t *__restrict_
 // Here the four 16-lane rows of a wavefront each own one system: lane (grp, c) holds columns
 // {c, 16+c, 32+c, ...} of system `grp`, one ds_swizzle row-broadcast serves all four systems and
 // feeds up to NT FMAs per lane, and the back substitution reduces inside the 16-lane row with DPP.
-// The four Grams are still accumulated one after the other with the full-wave MFMA of gram_row().
-template <int... Is, typename Fn>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, Fn &&f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename Fn> __device__ __forceinline__ void static_for(Fn &&f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
+// The four Grams are accumulated one after the other by ONE gram_ring() stream that runs across the
+// row boundaries (the rows are adjacent in CSR), so the gather pipeline never drains inside a quad.
+
 // value of lane SRC (0..15) of the caller's own 16-lane row (ds_swizzle bit mode, no LDS memory)
 template <int SRC> __device__ __forceinline__ float row_bcast(float v) {
     constexpr int pattern = (SRC << 5) | 0x10;          // and_mask = 0x10, or_mask = SRC, xor_mask = 0
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), pattern));
 }
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+
+template <int NT> __device__ __forceinline__ constexpr int quad_slab_floats() {
+    // column-major slab holding only the upper tiles: column 16q+c keeps rows 0..16q+15 (+4 pad)
+    int n = 0;
+    for (int q = 0; q < NT; q++) n += kTile * (kTile * (q + 1) + 4);
+    return n;
 }
-__device__ __forceinline__ float row16_allsum_dpp(float v) {
-    v += dpp_mov<0xB1>(v);      // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);      // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);     // row_half_mirror
-    v += dpp_mov<0x140>(v);     // row_mirror
-    return v;
+template <int NT> __device__ __forceinline__ constexpr int quad_slab_col_offset(int q) {
+    int n = 0;
+    for (int i = 0; i < q; i++) n += kTile * (kTile * (i + 1) + 4);
+    return n;
 }
 
-template <int NT, int KMAX>
+// Stream over the (up to) four rows of a quad: each row padded to a multiple of D groups.
+struct QuadStream {
+    uint32_t pr[5];   // CSR pointers of the quad's rows (wave-uniform)
+    uint32_t step;    // entries per iteration = 4 * D
+    __device__ __forceinline__ uint32_t row_ptr_at(int i) const {
+        return i == 0 ? pr[0] : i == 1 ? pr[1] : i == 2 ? pr[2] : i == 3 ? pr[3] : pr[4];
+    }
+    __device__ __forceinline__ GramDesc first() const {
+        GramDesc d{0, 0, -1};
+        for (int r = 0; r < 4; r++)
+            if (row_ptr_at(r + 1) > row_ptr_at(r)) { d = GramDesc{row_ptr_at(r), row_ptr_at(r + 1), r}; break; }
+        return d;
+    }
+    __device__ __forceinline__ void operator()(GramDesc &d) const {
+        if (d.row < 0) return;
+        d.e0 += step;
+        if (d.e0 < d.end) return;
+        int r = d.row + 1;
+        while (r < 4 && row_ptr_at(r + 1) == row_ptr_at(r)) r++;       // skip empty rows (trmf.cpp:374)
+        if (r < 4) d = GramDesc{row_ptr_at(r), row_ptr_at(r + 1), r};
+        else d = GramDesc{0, 0, -1};
+    }
+};
+
+// ABL: compile-time ablation mask for profiling (bit0 skip Gram, bit1 skip factorisation, bit2 skip back solve)
+template <int NT, int KMAX, int ABL = 0>
 __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,
                                                           const float *__restrict__ val,
                                                           const float *__restrict__ X,
                                                           float *__restrict__ F, uint32_t row_begin,
-                                                          uint32_t row_end, int k, float lambda) {
+                                                          uint32_t row_end, int k, float lambda,
+                                                          uint32_t zero_row) {
     static_assert(sizeof(real) == 4, "quad F-solve is the fp32 path");
-    constexpr int KP = kTile * NT, LDC = KP + 4;        // column-major slab: S[col * LDC + row]
-    __shared__ __attribute__((aligned(16))) float lds[4][KP * LDC];
+    constexpr int KP = kTile * NT;
+    constexpr int SLAB = quad_slab_floats<NT>();
+    __shared__ __attribute__((aligned(16))) float lds_slab[4][SLAB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 4, c = lane & 15;
     const uint32_t row0 = row_begin + (blockIdx.x * 4u + (uint32_t)wave) * 4u;
     if (row0 >= row_end) return;                        // wave-uniform; no block barrier below
-    float *S = lds[wave];
+    float *S = lds_slab[wave];
     typedef float f4 __attribute__((ext_vector_type(4)));
 
     // areg[q][s] = A[s][16q + c] of this lane row's system; only s <= 16q+15 is ever touched
@@ -311,40 +389,38 @@ __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__rest
     }
     bool mine = false;
 
+    QuadStream stream;
+    stream.step = 4u * kRingDepth;
+    {   // row pointers of the quad as wave-uniform scalars
+        const uint32_t rr = row0 + (uint32_t)(lane < 5 ? lane : 4);
+        const uint32_t v = ptr[rr < row_end ? rr : row_end];
 #pragma unroll
-    for (int sys = 0; sys < 4; sys++) {
-        const uint32_t row = row0 + (uint32_t)sys;
-        uint32_t p0 = 0, p1 = 0;
-        if (row < row_end) { p0 = ptr[row]; p1 = ptr[row + 1]; }
-        if (p0 == p1) continue;                         // trmf.cpp:374 (wave-uniform)
-        GramState<NT> st;
-#pragma unroll
-        for (int t = 0; t < NT * (NT + 1) / 2; t++) st.acc[t] = typename Mfma16<real>::acc_t{0, 0, 0, 0};
-        real nowq[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) { st.b[q] = 0; nowq[q] = 0; }
-        st.loss = 0;
-        gram_row<NT, true, false>(st, idx, val, X, p0, p1, 0, 1, lane, nowq);
+        for (int i = 0; i < 5; i++) stream.pr[i] = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
+    }
+
+    GramState<NT> st;
+    st.clear();
+    // system `sys` is complete in st: + lambda on the diagonal (trmf.cpp:393), accumulators -> slab
+    // (4 consecutive rows per store), then lane row `sys` pulls its columns into registers
+    auto finalize = [&](int sys) {
 #pragma unroll
         for (int q = 0; q < NT; q++) {
             st.b[q] += __shfl_xor(st.b[q], 16, kWave);
             st.b[q] += __shfl_xor(st.b[q], 32, kWave);
         }
-        // + lambda on the diagonal (trmf.cpp:393), then accumulators -> slab, 4 consecutive rows per store
-        {
-            int t = 0;
+        int t = 0;
 #pragma unroll
-            for (int ti = 0; ti < NT; ti++)
+        for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-                for (int tj = ti; tj < NT; tj++, t++) {
-                    f4 v = st.acc[t];
-                    if (ti == tj) {
+            for (int tj = ti; tj < NT; tj++, t++) {
+                f4 v = st.acc[t];
+                if (ti == tj) {
 #pragma unroll
-                        for (int r = 0; r < 4; r++) if (c == 4 * grp + r) v[r] += lambda;
-                    }
-                    *reinterpret_cast<f4 *>(&S[(kTile * tj + c) * LDC + kTile * ti + 4 * grp]) = v;
+                    for (int r = 0; r < 4; r++)   // pad rows get a unit diagonal: their steps are no-ops
+                        if (c == 4 * grp + r) v[r] += (kTile * ti + c < k) ? lambda : 1.0f;
                 }
-        }
+                *reinterpret_cast<f4 *>(&S[quad_slab_col_offset<NT>(tj) + c * (kTile * (tj + 1) + 4) + kTile * ti + 4 * grp]) = v;
+            }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (grp == sys) {
@@ -352,11 +428,10 @@ __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__rest
 #pragma unroll
             for (int q = 0; q < NT; q++) {
                 bz[q] = st.b[q];
-                constexpr int dummy = 0; (void)dummy;
 #pragma unroll
                 for (int s4 = 0; s4 < KMAX / 4; s4++) {
                     if (4 * s4 <= kTile * q + 15) {
-                        const f4 v = *reinterpret_cast<const f4 *>(&S[(kTile * q + c) * LDC + 4 * s4]);
+                        const f4 v = *reinterpret_cast<const f4 *>(&S[quad_slab_col_offset<NT>(q) + c * (kTile * (q + 1) + 4) + 4 * s4]);
                         areg[q][4 * s4 + 0] = v[0]; areg[q][4 * s4 + 1] = v[1];
                         areg[q][4 * s4 + 2] = v[2]; areg[q][4 * s4 + 3] = v[3];
                     }
@@ -365,15 +440,26 @@ __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__rest
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        st.clear();
+    };
+
+    if constexpr (!(ABL & 1)) {
+        float nowq[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) nowq[q] = 0;
+        gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, stream.first(), stream,
+                                               finalize);
     }
 
     // ---- four right-looking Cholesky factorisations side by side, forward substitution fused ----
     float dinv[NT];
 #pragma unroll
     for (int q = 0; q < NT; q++) dinv[q] = 0;
+    if constexpr (!(ABL & 2))
     static_for<KMAX>([&](auto J) {
         constexpr int j = decltype(J)::value, qj = j >> 4, cj = j & 15;
-        if (j < k) {
+        {   // no k-guard: rows >= k are identity rows (see finalize), so the whole factorisation is
+            // one straight-line block the scheduler can software-pipeline
             const float inv = inv_sqrt(row_bcast<cj>(areg[qj][j]));
             float u[NT];
 #pragma unroll
@@ -401,9 +487,10 @@ __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__rest
     float x[NT];
 #pragma unroll
     for (int q = 0; q < NT; q++) x[q] = 0;
+    if constexpr (!(ABL & 4))
     static_for<KMAX>([&](auto Jr) {
         constexpr int j = KMAX - 1 - decltype(Jr)::value, qj = j >> 4, cj = j & 15;
-        if (j < k) {
+        {
             float part = 0;
 #pragma unroll
             for (int q = qj; q < NT; q++) part = fmaf(areg[q][j], x[q], part);
@@ -418,7 +505,6 @@ __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__rest
             if (kTile * q + c < k) F[(size_t)(row0 + grp) * KP + kTile * q + c] = x[q];
     }
 }
-
 #endif  // TRMF_F32
 
 // ---- X-side Gram cache: one workgroup (4 waves) per timestamp row ---------------------------------
@@ -430,7 +516,8 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
                                                      const real *__restrict__ W,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      double *__restrict__ lossrow,
-                                                     uint32_t row_begin, uint32_t row_end, int k) {
+                                                     uint32_t row_begin, uint32_t row_end, int k,
+                                                     uint32_t zero_row) {
     constexpr int KP = kTile * NT, LD = KP + 1;
     __shared__ real S[KP * LD];
     __shared__ real Sb[KP];
@@ -442,14 +529,17 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
     const uint32_t p0 = ptr[row], p1 = ptr[row + 1];
 
     GramState<NT> st;
-#pragma unroll
-    for (int t = 0; t < NT * (NT + 1) / 2; t++) st.acc[t] = typename Mfma16<real>::acc_t{0, 0, 0, 0};
+    st.clear();
     real wq[NT];
 #pragma unroll
-    for (int q = 0; q < NT; q++) { st.b[q] = 0; wq[q] = W[(size_t)row * KP + kTile * q + c]; }
-    st.loss = 0;
-    gram_row<NT, true, true>(st, idx, val, Hf, p0, p1, wave, 4, lane, wq);
-
+    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + kTile * q + c];
+    {   // this wavefront takes groups wave, wave+4, ... of the row
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p0 + 4u * (uint32_t)wave));
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
+        GramDesc d0{e0, e1, e0 < e1 ? 0 : -1};
+        gram_ring<NT, kRingDepth, true, true>(st, idx, val, Hf, zero_row, 16u, lane, wq, d0,
+                                              SingleRowStream{16u * kRingDepth}, [](int) {});
+    }
 #pragma unroll
     for (int q = 0; q < NT; q++) {
         st.b[q] += __shfl_xor(st.b[q], 16, kWave);
@@ -498,7 +588,8 @@ __global__ __launch_bounds__(256) void loss_kernel(const uint32_t *__restrict__ 
                                                    const real *__restrict__ Hf,
                                                    const real *__restrict__ W,
                                                    double *__restrict__ lossrow,
-                                                   uint32_t row_begin, uint32_t row_end) {
+                                                   uint32_t row_begin, uint32_t row_end,
+                                                   uint32_t zero_row) {
     constexpr int KP = kTile * NT;
     __shared__ double Sl[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -507,11 +598,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const uint32_t *__restrict__ 
     if (row >= row_end) return;
     const uint32_t p0 = ptr[row], p1 = ptr[row + 1];
     GramState<NT> st;
+    st.clear();
     real wq[NT];
 #pragma unroll
-    for (int q = 0; q < NT; q++) { st.b[q] = 0; wq[q] = W[(size_t)row * KP + kTile * q + c]; }
-    st.loss = 0;
-    gram_row<NT, false, true>(st, idx, val, Hf, p0, p1, wave, 4, lane, wq);
+    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + kTile * q + c];
+    {
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p0 + 4u * (uint32_t)wave));
+        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
+        GramDesc d0{e0, e1, e0 < e1 ? 0 : -1};
+        gram_ring<NT, kRingDepth, false, true>(st, idx, val, Hf, zero_row, 16u, lane, wq, d0,
+                                               SingleRowStream{16u * kRingDepth}, [](int) {});
+    }
     double l = (c == 0) ? st.loss : 0.0;
     l = wave_allsum(l);
     if (lane == 0) Sl[wave] = l;

@@ -95,8 +95,9 @@ struct TrmfSessionImpl {
     double *P(int slot) { return partials.p + (size_t)slot * kMaxPartials; }
 
     // ---------------------------------------------------------------------------------------------
+    // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).
     int upload_padded(DevBuf<real> &dst, const real *src, size_t rows) {
-        std::vector<real> tmp(rows * (size_t)KP, real(0));
+        std::vector<real> tmp((rows + 1) * (size_t)KP, real(0));
         for (size_t i = 0; i < rows; i++) std::memcpy(&tmp[i * KP], src + i * (size_t)k, sizeof(real) * k);
         return dst.upload(tmp.data(), tmp.size());
     }
@@ -119,6 +120,7 @@ struct TrmfSessionImpl {
         nlag = (int)lag_size; midx = nlag ? (int)lags[nlag - 1] : 0;
         comm = active_comm();
         if (const char *e = getenv("TRMF_FSOLVE")) use_quad = use_quad && std::string(e) != "wave";
+        if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
         host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
@@ -175,20 +177,37 @@ struct TrmfSessionImpl {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
         hipLaunchKernelGGL((fsolve_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
-                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI);
+                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
         return 0;
     }
     template <int NT_, int KMAX_> int launch_fsolve_quad(uint32_t rb, uint32_t re) {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
 #if defined(TRMF_F32)
-        hipLaunchKernelGGL((fsolve_quad_kernel<NT_, KMAX_>), dim3((rows + 15) / 16), dim3(256), 0, stream,
-                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI);
+        const dim3 grid((rows + 15) / 16), block(256);
+#define TRMF_LAUNCH_QUAD(ABL)                                                                          \
+        hipLaunchKernelGGL((fsolve_quad_kernel<NT_, KMAX_, ABL>), grid, block, 0, stream, Yc_ptr.p,    \
+                           Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T)
+#if defined(TRMF_ABLATION)
+        if (NT_ == 3 && KMAX_ == 40 && dbg_flags) {
+            switch (dbg_flags) {
+                case 1: TRMF_LAUNCH_QUAD(1); break;
+                case 2: TRMF_LAUNCH_QUAD(2); break;
+                case 4: TRMF_LAUNCH_QUAD(4); break;
+                case 6: TRMF_LAUNCH_QUAD(6); break;
+                default: TRMF_LAUNCH_QUAD(7); break;
+            }
+            return 0;
+        }
+#endif
+        TRMF_LAUNCH_QUAD(0);
+#undef TRMF_LAUNCH_QUAD
 #endif
         return 0;
     }
     // fp32: four systems per wavefront (fsolve_quad_kernel); fp64 or TRMF_FSOLVE=wave: one per wavefront
     bool use_quad = sizeof(real) == 4;
+    int dbg_flags = 0;           // TRMF_DEBUG_ABLATE: bit0 skip Gram, bit1 skip factorisation, bit2 skip back-solve
     int fsolve(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
@@ -225,12 +244,12 @@ struct TrmfSessionImpl {
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
         if (re > rb)
             hipLaunchKernelGGL((gram_x_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
-                               Yr_val.p, H.p, W.p, G.p, Bv.p, lossrow.p, rb, re, k);
+                               Yr_val.p, H.p, W.p, G.p, Bv.p, lossrow.p, rb, re, k, (uint32_t)n);
     }
     template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
         if (re > rb)
             hipLaunchKernelGGL((loss_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
-                               Yr_val.p, H.p, Wv, lossrow.p, rb, re);
+                               Yr_val.p, H.p, Wv, lossrow.p, rb, re, (uint32_t)n);
     }
     int gram_x() {
         const uint32_t rb = (uint32_t)xbounds[comm->rank], re = (uint32_t)xbounds[comm->rank + 1];
