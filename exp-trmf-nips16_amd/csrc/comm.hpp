@@ -23,6 +23,7 @@ namespace trmf {
 
 struct Comm {
     int rank = 0, world = 1;
+    bool call_when_single = false;   // issue the (degenerate) gather even for world == 1
     virtual ~Comm() {}
     // Gather in place: rank r owns bytes [off[r], off[r+1]) of dbuf (device memory).
     virtual int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) = 0;
@@ -94,6 +95,7 @@ inline RcclApi &rccl_api() { static RcclApi api; return api; }
 
 struct RcclComm : Comm {
     RcclApi::CommT comm = nullptr;
+    RcclComm() { call_when_single = true; }   // keeps the RCCL call path testable on a 1-GPU box
     ~RcclComm() override { if (comm) rccl_api().CommDestroy(comm); }
     int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) override {
         RcclApi &api = rccl_api();

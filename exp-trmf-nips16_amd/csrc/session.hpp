@@ -166,7 +166,7 @@ struct TrmfSessionImpl {
 
     // ---- all-gather helpers ------------------------------------------------------------------------
     int gather_rows(void *dbuf, const std::vector<uint64_t> &bounds, size_t row_bytes) {
-        if (comm->world == 1) return 0;
+        if (comm->world == 1 && !comm->call_when_single) return 0;
         std::vector<uint64_t> off(bounds.size());
         for (size_t i = 0; i < bounds.size(); i++) off[i] = bounds[i] * row_bytes;
         return comm->allgatherv(dbuf, off.data(), stream);

@@ -1,0 +1,76 @@
+"""Worker for the world_size>1 tests (launched by test_dist_*.py through torch.multiprocessing)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (os.path.join(ROOT, 'exp-trmf-nips16_amd'), os.path.join(ROOT, 'oracle'), os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _problem():
+    from trmf import synth
+    p = synth.sparse_problem(n=900, T=400, k=12, nlag=4, density=0.06, dtype=np.float64, seed=21)
+    m = synth.initial_model(p['Y'], p['lag_set'], 12, seed=21)
+    return p, m
+
+
+def cpu_sharded_fsolve(rank, world, port, out):
+    """gloo, CPU only: every rank solves ITS row block of the F-solve (partition from the library's
+    host logic) with the oracle, blocks are all-gathered in the library's layout; the result must be
+    bit-identical to the unsharded solve."""
+    import torch
+    import torch.distributed as dist
+    import oracle_py as O
+    import scipy.sparse as smat
+    from trmf import session, synth
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
+    p, m = _problem()
+    Yc = smat.csc_matrix(p['Y'])
+    Yt = smat.csr_matrix((Yc.data, Yc.indices, Yc.indptr), shape=(Yc.shape[1], Yc.shape[0]))   # items x timestamps
+    bounds = session.partition_by_nnz(Yc.indptr, world, dtype=np.float64)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    H = m.H.copy()
+    blk = H[lo:hi].copy()
+    O.fsolve_port(Yt[lo:hi], m.W, blk, synth.HYPER['lambdaI'])
+    H[lo:hi] = blk
+    # all-gather of uneven row blocks, root = owner (same protocol as csrc/comm.hpp)
+    k = H.shape[1]
+    for r in range(world):
+        a, b = int(bounds[r]), int(bounds[r + 1])
+        if b > a:
+            piece = torch.from_numpy(H[a:b].copy() if r == rank else np.empty((b - a, k)))
+            dist.broadcast(piece, src=r)
+            H[a:b] = piece.numpy()
+    ref = m.H.copy()
+    O.fsolve_port(Yt, m.W, ref, synth.HYPER['lambdaI'])
+    ok = bool(np.array_equal(H, ref)) and int(bounds[0]) == 0 and int(bounds[-1]) == Yt.shape[0]
+    if rank == 0:
+        out.put(('cpu_sharded_fsolve', ok, [int(b) for b in bounds]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def gpu_host_staged(rank, world, port, out, iters):
+    """Two processes on ONE GPU, host-staged all-gather over gloo: the sharded device path must give
+    results bit-identical across ranks and equal to the single-process run."""
+    import torch.distributed as dist
+    from trmf import dist as tdist, session, synth
+    from helpers import make_model
+    dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
+    res = {}
+    for dtype in (np.float32, np.float64):
+        p, m0 = _problem()
+        Y = p['Y'].astype(dtype)
+        W0, H0, T0 = m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype))
+        tdist.init_host_staged(dtype)
+        model = make_model(W0, H0, T0, p['lag_set'])
+        with session.Session(Y, model, missing=True, **synth.HYPER) as s:
+            s.run(iters); st = s.stats(iters); s.download()
+        tdist.finalize(dtype)
+        res[np.dtype(dtype).name] = (model.W.copy(), model.H.copy(), model.lag_val.copy(), [x['cg_iter'] for x in st])
+    out.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()

@@ -1,0 +1,108 @@
+"""World_size-2 coverage of the sharded ALS loop.
+
+* CPU / gloo (`-m "not gpu"`): the library's partitioner + the all-gather layout, with the oracle
+  doing the arithmetic of each shard (the product has no CPU compute path).
+* GPU (`-m gpu`): two processes share the one GPU of the box and exchange blocks through the
+  host-staged communicator (gloo); the device kernels run on each rank's shard.  The RCCL
+  communicator itself needs >= 2 GPUs and is exercised by bench.py --gpus N on the driver's node;
+  with one rank it is covered below (all-gather degenerates to a no-op)."""
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import make_model, relfro
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    return port
+
+
+def _spawn(fn, world, *args):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=fn, args=(r, world, port, q) + args) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(1 if fn.__name__ == 'cpu_sharded_fsolve' else world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    return out
+
+
+def test_gloo_world2_sharded_fsolve_matches_unsharded():
+    import dist_worker
+    (name, ok, bounds), = _spawn(dist_worker.cpu_sharded_fsolve, 2)
+    assert ok, bounds
+    assert 0 < bounds[1] < bounds[2]
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_match_single_process():
+    import dist_worker
+    from trmf import session, synth
+    iters = 3
+    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters))
+    p, m0 = dist_worker._problem()
+    for dtype in (np.float32, np.float64):
+        name = np.dtype(dtype).name
+        W0, H0, T0 = m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype))
+        model = make_model(W0, H0, T0, p['lag_set'])
+        with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
+            s.run(iters); st = s.stats(iters); s.download()
+        for r in (0, 1):
+            W, H, Th, cg = out[r][name]
+            # every kernel is deterministic and the CG runs replicated: bit-identical everywhere
+            assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val)
+            assert cg == [x['cg_iter'] for x in st]
+
+
+RCCL_SCRIPT = r"""
+import sys, os, ctypes
+ROOT = sys.argv[1]
+for p in (os.path.join(ROOT, 'exp-trmf-nips16_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+if sys.argv[2] == 'torch_first':
+    import torch                      # one HIP/RCCL runtime per process: torch's, loaded first
+    torch.cuda.init()
+import numpy as np
+from trmf import session, synth
+from helpers import make_model
+lib = session.lib_for(np.float32)
+buf = ctypes.create_string_buffer(128)
+assert lib.trmf_dist_get_unique_id(buf) == 0, lib.trmf_last_error()
+assert lib.trmf_dist_init(0, 1, buf.raw) == 0, lib.trmf_last_error()
+assert lib.trmf_dist_world() == 1 and lib.trmf_dist_rank() == 0
+p = synth.sparse_problem(n=500, T=300, k=8, nlag=3, density=0.05, dtype=np.float32, seed=2)
+m = synth.initial_model(p['Y'], p['lag_set'], 8, seed=2)
+a = make_model(m.W, m.H, m.lag_val, p['lag_set'])
+with session.Session(p['Y'], a, missing=True, **synth.HYPER) as s:
+    s.run(2); s.download()
+lib.trmf_dist_finalize()
+b = make_model(m.W, m.H, m.lag_val, p['lag_set'])
+with session.Session(p['Y'], b, missing=True, **synth.HYPER) as s:
+    s.run(2); s.download()
+assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H)
+print('RCCL_OK')
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('order', ['torch_first', 'standalone'])
+def test_rccl_single_rank_communicator(order):
+    """RCCL bootstrap + communicator lifecycle with world == 1 (all a one-GPU box can run), in a
+    fresh process for each supported load order: torch imported first (bench.py --gpus N: the process
+    binds to torch's bundled HIP/RCCL) or no torch at all (/opt/rocm's HIP/RCCL).  Loading this
+    library first and torch afterwards puts two HIP runtimes in one process and is not supported."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run([sys.executable, '-c', RCCL_SCRIPT, root, order], capture_output=True, text=True,
+                         timeout=400, env=env)
+    assert 'RCCL_OK' in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
