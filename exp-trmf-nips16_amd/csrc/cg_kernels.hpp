@@ -202,6 +202,129 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     if (threadIdx.x == 0) Pdot[blockIdx.x] = dot;
 }
 
+// ---- fused Hessian-vector / gradient kernel, tiled over time in LDS --------------------------------
+// One launch = [direction update (FUSE_DIR)] + AR residual + AR adjoint + cached-Gram product
+// (ar_residual_kernel + apply_kernel above, same arithmetic and rounding sequence).  A workgroup owns
+// TI consecutive timestamps: it stages the operand rows [i0-midx, i0+TI+midx) in LDS, forms the AR
+// residuals of rows [i0, i0+TI+midx) there (the halo is recomputed, not exchanged), and then streams
+// its TI cached Grams once.  Used when the halo fits LDS (hv_tile_lds_bytes); otherwise the two-kernel
+// path runs.  dynamic LDS = hv_tile_lds_bytes(TI, midx, KP)
+__host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, int nlag = 0, int k = 0) {
+    const size_t a = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;
+    const size_t b = ((size_t)(TI + midx) * KP * sizeof(double) + 15) / 16 * 16;
+    return a + b + (size_t)nlag * k * sizeof(real) + (size_t)nlag * sizeof(int);   // + Theta, lag_set
+}
+
+template <bool FUSE_DIR>
+__global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *__restrict__ st,
+                                                      const double *__restrict__ Prr_cur,
+                                                      const double *__restrict__ Prr_prev, int np,
+                                                      const real *__restrict__ v,
+                                                      const real *__restrict__ rvec,
+                                                      real *__restrict__ dnew,
+                                                      const uint32_t *__restrict__ lag_set,
+                                                      const real *__restrict__ theta,
+                                                      const real *__restrict__ G,
+                                                      const real *__restrict__ Bv, int minus_b,
+                                                      real *__restrict__ out, int dot_mode,
+                                                      double *__restrict__ Pbase, int TI, int rpb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
+    __shared__ double smem[256];
+    real tmp = 0;
+    if (Prr_cur != nullptr) {
+        const real rho = (real)sum_partials(Prr_cur, np, smem);
+        if (cg_stopped(rho, st->cgtol)) return;
+        if (FUSE_DIR) {
+            const real rho_prev = (real)sum_partials(Prr_prev, np, smem);
+            const real beta = rho / rho_prev;                                // rf_tron.h:495
+            tmp = beta - (real)1.0;                                          // rf_tron.h:497
+        }
+    }
+    const int k = p.k, KP = p.KP, T = p.T, Hh = p.midx, nlag = p.nlag;
+    const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
+    real *vs = reinterpret_cast<real *>(hv_smem);
+    double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
+    real *ths = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
+    int *lags = reinterpret_cast<int *>(ths + (size_t)nlag * k);
+    for (int e = threadIdx.x; e < nlag * k; e += 256) ths[e] = theta[e];     // Theta(l,t) at ths[t*nlag+l]
+    for (int e = threadIdx.x; e < nlag; e += 256) lags[e] = (int)lag_set[e];
+    const bool ar_on = nlag > 0 && p.lambdaAR > 0;
+    double ar2 = 0, vv = 0, dot = 0;
+    const int ntiles = (T + TI - 1) / TI;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int i0 = tile * TI, i1 = min(i0 + TI, T);
+        __syncthreads();
+        // (1) operand rows -> LDS (zero outside [0,T)); FUSE_DIR: d_new = d + (beta-1) d + r
+        for (int e = threadIdx.x; e < rowsV * KP; e += 256) {
+            const int rr = e / KP, t = e - rr * KP, i = i0 - Hh + rr;
+            real x = 0;
+            if (i >= 0 && i < T) {
+                x = v[(size_t)i * KP + t];
+                if (FUSE_DIR) { x = fma(tmp, x, x); x = x + rvec[(size_t)i * KP + t]; }
+                if (i >= i0 && i < i1) {
+                    if (FUSE_DIR) dnew[(size_t)i * KP + t] = x;
+                    vv += (double)x * (double)x;
+                }
+            }
+            vs[e] = x;
+        }
+        __syncthreads();
+        // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139)
+        for (int e = threadIdx.x; e < rowsR * KP; e += 256) {
+            const int rr = e / KP, t = e - rr * KP, i = i0 + rr;
+            double res = 0;
+            if (ar_on && t < k && i >= Hh && i < T) {
+                res = (double)vs[(rr + Hh) * KP + t];
+                for (int l = 0; l < nlag; l++) {
+                    const real prod = ths[t * nlag + l] * vs[(rr + Hh - lags[l]) * KP + t];
+                    res -= (double)prod;
+                }
+                if (rr < TI) ar2 += res * res;
+            }
+            rs[e] = res;
+        }
+        __syncthreads();
+        // (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b), `rpb` rows per pass.  The cached Gram is the
+        //     only HBM-sized stream of the CG: kGChunk loads are kept in flight per thread.
+        const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;
+        for (int r0 = 0; r0 < TI; r0 += rpb) {
+            const int rr = r0 + lr, i = i0 + rr;
+            if (lr < rpb && rr < TI && i < T) {
+                const real x = vs[(rr + Hh) * KP + t];
+                const real *Gi = G + (size_t)i * k * k + t;
+                const real *vi = vs + (rr + Hh) * KP;
+                double acc = 0;
+#pragma unroll 8
+                for (int s2 = 0; s2 < k; s2++) acc += (double)Gi[(size_t)s2 * k] * (double)vi[s2];
+                real o;
+                if (p.lambdaI == 0) o = 0;
+                else if (p.lambdaI == 1) o = x;
+                else o = (real)(p.lambdaI * (double)x);
+                if (ar_on) {
+                    if (i >= Hh) o = (real)((double)o + p.lambdaAR * rs[rr * KP + t]);
+                    for (int l = 0; l < nlag; l++) {
+                        const int ii = i + lags[l];
+                        if (ii >= Hh && ii < T)
+                            o = (real)((double)o - p.lambdaAR * rs[(rr + lags[l]) * KP + t] * (double)ths[t * nlag + l]);
+                    }
+                }
+                if (minus_b) acc -= (double)Bv[(size_t)i * KP + t];
+                o = (real)((double)o + acc);
+                out[(size_t)i * KP + t] = o;
+                dot += (double)(dot_mode ? x : o) * (double)o;
+            }
+        }
+    }
+    ar2 = block_allsum(ar2, smem);
+    vv = block_allsum(vv, smem);
+    dot = block_allsum(dot, smem);
+    if (threadIdx.x == 0) {
+        Pbase[P_AR * kMaxPartials + blockIdx.x] = ar2;
+        Pbase[P_VV * kMaxPartials + blockIdx.x] = vv;
+        Pbase[P_DOT * kMaxPartials + blockIdx.x] = dot;
+    }
+}
+
 // ---- CG initialisation: f, |g|, tolerances; s = 0, r = -g, d = r  (rf_tron.h:154-169, 424-439) ----
 __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restrict__ st,
                                                       double *__restrict__ Pbase, int np_base,
@@ -292,24 +415,25 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const real *__rest
 }
 
 // ---- acceptance test and commit (rf_tron.h:191-229) -------------------------------------------------
-// Every block derives the same decision; block 0 records the TRON line values.
+// The X sub-problem is exactly quadratic, so f(w+s) - f(w) = g.s + 1/2 s.Hs.  The reference evaluates
+// fun(w+s) with another full pass over the observations (rf_tron.h:191 -> trmf.cpp:231-245); here one
+// extra Hessian-vector product H s (cached Grams, no gather) gives the same reduction without the
+// cancellation of subtracting two large objective values.  Every block derives the same decision;
+// block 0 records the TRON line values.
 __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restrict__ st,
                                                      const double *__restrict__ Pbase, int np,
-                                                     const double *__restrict__ Prr_final,
+                                                     int np_dot, const double *__restrict__ Prr_final,
                                                      const real *__restrict__ w_new,
                                                      real *__restrict__ w) {
     __shared__ double smem[256];
-    const double ar2 = sum_partials(Pbase + P_AR * kMaxPartials, np, smem);
-    const double vv = sum_partials(Pbase + P_VV * kMaxPartials, np, smem);
     const double gs = (double)(real)sum_partials(Pbase + P_GS * kMaxPartials, np, smem);
     const double sr = (double)(real)sum_partials(Pbase + P_SR * kMaxPartials, np, smem);
+    const double sHs = sum_partials(Pbase + P_DOT * kMaxPartials, np_dot, smem);
     const double rho = (double)(real)sum_partials(Prr_final, np, smem);
-    double fnew = 0.5 * st->loss1;
-    if (p.lambdaI > 0) fnew += 0.5 * p.lambdaI * (double)(real)vv;
-    if (p.nlag > 0 && p.lambdaAR > 0) fnew += 0.5 * p.lambdaAR * ar2;
     const double f = st->f;
     const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190
-    const double actred = f - fnew;
+    const double actred = -(gs + 0.5 * sHs);                                 // = f - f(w+s), exactly
+    const double fnew = f - actred;
     const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
     if (accept) {
         const size_t N = (size_t)p.T * p.KP;

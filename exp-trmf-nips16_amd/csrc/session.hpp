@@ -82,6 +82,7 @@ struct TrmfSessionImpl {
     std::vector<PhaseEvents> events;
     static constexpr int kEventRing = 64;
     int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
+    int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), grid
     XParams xp{};
 
     ~TrmfSessionImpl() {
@@ -148,6 +149,13 @@ struct TrmfSessionImpl {
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
         nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
+        {   // fused Hv tile: two passes of `rpb` rows, if the AR halo fits a modest LDS budget
+            const int TI = 2 * rpb;
+            if (hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
+                tile_TI = TI;
+                nbt = std::min(kMaxPartials, (T + TI - 1) / TI);
+            }
+        }
         xp.T = T; xp.k = k; xp.KP = KP; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
 
@@ -278,44 +286,61 @@ struct TrmfSessionImpl {
     }
 
     // ---- X-solve (trmf.cpp:665-674 -> rf_tron.h:134-254) -----------------------------------------------
+    // out = H*v (or the gradient when minus_b): fused LDS-tiled kernel when the AR halo fits, else the
+    // ar_residual + apply pair.  `fuse`: v is the previous direction and the new one is formed on the fly.
+    int hv(const real *v, bool fuse, const real *rvec, real *dnew, const double *Pcur, const double *Pprev,
+           int minus_b, real *out, int dot_mode) {
+        XState *st = xstate.p;
+        double *Pb = partials.p;
+        if (tile_TI > 0) {
+            const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
+            if (fuse)
+                hipLaunchKernelGGL((hv_tile_kernel<true>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, nbe,
+                                   v, rvec, dnew, lag_set.p, theta.p, G.p, Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
+            else
+                hipLaunchKernelGGL((hv_tile_kernel<false>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, nbe,
+                                   v, rvec, dnew, lag_set.p, theta.p, G.p, Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
+        } else {
+            if (fuse)
+                hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
+                                   v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
+            else
+                hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
+                                   v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
+            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
+                               lag_set.p, theta.p, G.p, Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb);
+        }
+        return 0;
+    }
+    int np_base() const { return tile_TI > 0 ? nbt : nbe; }   // blocks that wrote P_AR / P_VV
+    int np_dot() const { return tile_TI > 0 ? nbt : nba; }    // blocks that wrote P_DOT
+
     int xsolve() {
         XState *st = xstate.p;
         double *Pb = partials.p;
         if (gram_x()) return kFail;                                            // G, b, loss(w)
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss0);
-        hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st,
-                           (const double *)nullptr, (const double *)nullptr, 0, W.p, (const real *)nullptr,
-                           (real *)nullptr, lag_set.p, theta.p, rAR.p, Pb);
-        hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, (const double *)nullptr, 0,
-                           W.p, rAR.p, lag_set.p, theta.p, G.p, Bv.p, 1, g.p, 0, P(P_DOT), rpb);
-        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, g.p, s.p,
-                           r.p, d0.p);
+        hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0);           // gradient, <g,g>, AR/ridge sums
+        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, np_base(), np_dot(), g.p,
+                           s.p, r.p, d0.p);
         const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
         real *dcur = d0.p, *dalt = d1.p;
         for (int it = 0; it < maxcg; it++) {
             double *Pcur = P(P_RR0 + (it & 1)), *Pnext = P(P_RR0 + ((it + 1) & 1));
             if (it == 0) {
-                hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur,
-                                   (const double *)nullptr, nbe, dcur, (const real *)nullptr, (real *)nullptr,
-                                   lag_set.p, theta.p, rAR.p, Pb);
+                hv(dcur, false, nullptr, nullptr, Pcur, nullptr, 0, Hd.p, 1);
             } else {
-                hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur,
-                                   Pnext /* = rho[it-1] */, nbe, dcur, r.p, dalt, lag_set.p, theta.p, rAR.p, Pb);
+                hv(dcur, true, r.p, dalt, Pcur, Pnext /* = rho[it-1] */, 0, Hd.p, 1);
                 std::swap(dcur, dalt);
             }
-            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, dcur, rAR.p,
-                               lag_set.p, theta.p, G.p, Bv.p, 0, Hd.p, 1, P(P_DOT), rpb);
             hipLaunchKernelGGL(cg_update_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pnext, P(P_DOT),
-                               nbe, nba, it, dcur, Hd.p, s.p, r.p);
+                               nbe, np_dot(), it, dcur, Hd.p, s.p, r.p);
         }
         double *Pfinal = P(P_RR0 + (maxcg & 1));
         hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, W.p, s.p, g.p, r.p, w_new.p, Pb);
-        hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st,
-                           (const double *)nullptr, (const double *)nullptr, 0, w_new.p, (const real *)nullptr,
-                           (real *)nullptr, lag_set.p, theta.p, rAR.p, Pb);
-        if (loss(w_new.p, false)) return kFail;
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss1);
-        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, Pfinal, w_new.p, W.p);
+        hv(s.p, false, nullptr, nullptr, nullptr, nullptr, 0, Hd.p, 1);          // H s, <s,Hs>
+        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, np_dot(), Pfinal, w_new.p,
+                           W.p);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }
