@@ -194,7 +194,7 @@ def main():
                 args.config, cfg['n'], cfg['T'], cfg['density'], nnz, cfg['k'], cfg['nlag'], dtype.name,
                 hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
                 'parallelism': 'F rows / X-Gram rows sharded x{}, CG replicated'.format(world)},
-            'roofline': {'kernel': 'fsolve_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+            'roofline': {'kernel': 'fsolve_quad_kernel<3,40>' if dtype == np.float32 else 'fsolve_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
                          'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows'},

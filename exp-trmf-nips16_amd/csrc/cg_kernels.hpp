@@ -28,7 +28,7 @@ struct XState {
 enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_NSLOTS = 7 };
 
 struct XParams {
-    int T, k, KP, nlag, midx;
+    int T, k, KP, NT, nlag, midx;      // NT = KP/16: vectors use the column-interleaved layout (colpos)
     double lambdaI, lambdaAR, eps_cg;
 };
 
@@ -114,7 +114,8 @@ __global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XStat
     const size_t N = (size_t)p.T * p.KP;
     double ar2 = 0, vv = 0;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
-        const int i = (int)(e / p.KP), t = (int)(e - (size_t)i * p.KP);
+        const int i = (int)(e / p.KP), tp = (int)(e - (size_t)i * p.KP);   // tp: position in the row
+        const int t = collog(tp, p.NT);                                       // logical latent dimension
         const real x = operand(e);
         if (FUSE_DIR) dnew[e] = x;
         vv += (double)x * (double)x;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XStat
             res = (double)x;
             for (int l = 0; l < p.nlag; l++) {
                 const real prod = theta[(size_t)t * p.nlag + l] *
-                                  operand((size_t)(i - (int)lag_set[l]) * p.KP + t);
+                                  operand((size_t)(i - (int)lag_set[l]) * p.KP + tp);
                 res -= (double)prod;
             }
             ar2 += res * res;
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
         if (cg_stopped(rho, st->cgtol)) return;
     }
     const int k = p.k, KP = p.KP;
-    const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;
+    const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;     // t: logical column
+    const int tp = colpos(t, p.NT);                                 // its position in a vector row
     const bool active_lane = lr < rpb;
     double dot = 0;
     const int ngroups = (p.T + rpb - 1) / rpb;
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
         const int i = grp * rpb + lr;
         const bool active = active_lane && i < p.T;
         real x = 0;
-        if (active) x = v[(size_t)i * KP + t];
+        if (active) x = v[(size_t)i * KP + tp];
         __syncthreads();
         vs[threadIdx.x] = x;
         __syncthreads();
@@ -178,11 +180,11 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
             else if (p.lambdaI == 1) o = x;
             else o = (real)(p.lambdaI * (double)x);
             if (p.nlag > 0 && p.lambdaAR > 0) {
-                if (i >= p.midx) o = (real)((double)o + p.lambdaAR * rAR[(size_t)i * KP + t]);
+                if (i >= p.midx) o = (real)((double)o + p.lambdaAR * rAR[(size_t)i * KP + tp]);
                 for (int l = 0; l < p.nlag; l++) {
                     const int ii = i + (int)lag_set[l];
                     if (ii >= p.midx && ii < p.T)
-                        o = (real)((double)o - p.lambdaAR * rAR[(size_t)ii * KP + t] *
+                        o = (real)((double)o - p.lambdaAR * rAR[(size_t)ii * KP + tp] *
                                                    (double)theta[(size_t)t * p.nlag + l]);
                 }
             }
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
             for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k] * (double)vi[s];
             if (minus_b) acc -= (double)Bv[(size_t)i * KP + t];
             o = (real)((double)o + acc);
-            out[(size_t)i * KP + t] = o;
+            out[(size_t)i * KP + tp] = o;
             dot += (double)(dot_mode ? x : o) * (double)o;
         }
     }
@@ -271,12 +273,13 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
         __syncthreads();
         // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139)
         for (int e = threadIdx.x; e < rowsR * KP; e += 256) {
-            const int rr = e / KP, t = e - rr * KP, i = i0 + rr;
+            const int rr = e / KP, tp = e - rr * KP, i = i0 + rr;         // tp: position, t: logical column
+            const int t = collog(tp, p.NT);
             double res = 0;
             if (ar_on && t < k && i >= Hh && i < T) {
-                res = (double)vs[(rr + Hh) * KP + t];
+                res = (double)vs[(rr + Hh) * KP + tp];
                 for (int l = 0; l < nlag; l++) {
-                    const real prod = ths[t * nlag + l] * vs[(rr + Hh - lags[l]) * KP + t];
+                    const real prod = ths[t * nlag + l] * vs[(rr + Hh - lags[l]) * KP + tp];
                     res -= (double)prod;
                 }
                 if (rr < TI) ar2 += res * res;
@@ -286,31 +289,32 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
         __syncthreads();
         // (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b), `rpb` rows per pass.  The cached Gram is the
         //     only HBM-sized stream of the CG: kGChunk loads are kept in flight per thread.
-        const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;
+        const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;   // t: logical column
+        const int tp = colpos(t, p.NT);
         for (int r0 = 0; r0 < TI; r0 += rpb) {
             const int rr = r0 + lr, i = i0 + rr;
             if (lr < rpb && rr < TI && i < T) {
-                const real x = vs[(rr + Hh) * KP + t];
+                const real x = vs[(rr + Hh) * KP + tp];
                 const real *Gi = G + (size_t)i * k * k + t;
                 const real *vi = vs + (rr + Hh) * KP;
                 double acc = 0;
 #pragma unroll 8
-                for (int s2 = 0; s2 < k; s2++) acc += (double)Gi[(size_t)s2 * k] * (double)vi[s2];
+                for (int s2 = 0; s2 < k; s2++) acc += (double)Gi[(size_t)s2 * k] * (double)vi[colpos(s2, p.NT)];
                 real o;
                 if (p.lambdaI == 0) o = 0;
                 else if (p.lambdaI == 1) o = x;
                 else o = (real)(p.lambdaI * (double)x);
                 if (ar_on) {
-                    if (i >= Hh) o = (real)((double)o + p.lambdaAR * rs[rr * KP + t]);
+                    if (i >= Hh) o = (real)((double)o + p.lambdaAR * rs[rr * KP + tp]);
                     for (int l = 0; l < nlag; l++) {
                         const int ii = i + lags[l];
                         if (ii >= Hh && ii < T)
-                            o = (real)((double)o - p.lambdaAR * rs[(rr + lags[l]) * KP + t] * (double)ths[t * nlag + l]);
+                            o = (real)((double)o - p.lambdaAR * rs[(rr + lags[l]) * KP + tp] * (double)ths[t * nlag + l]);
                     }
                 }
                 if (minus_b) acc -= (double)Bv[(size_t)i * KP + t];
                 o = (real)((double)o + acc);
-                out[(size_t)i * KP + t] = o;
+                out[(size_t)i * KP + tp] = o;
                 dot += (double)(dot_mode ? x : o) * (double)o;
             }
         }

@@ -27,6 +27,12 @@ constexpr int kMaxPartials = 1024; // entries of every per-block partial-sum arr
 // Padded leading dimension of every factor / CG vector in HBM: k rounded up to the MFMA tile.
 __host__ __device__ constexpr int padded_rank(int k) { return ((k + kTile - 1) / kTile) * kTile; }
 
+// Column-interleaved factor layout.  Every T x KP / n x KP matrix in HBM stores logical column t at
+// position colpos(t): the NT = KP/16 columns {c, 16+c, 32+c, ...} that one MFMA lane needs sit next to
+// each other, so a lane fetches its operand slices of a gathered row with ONE vector load.
+__host__ __device__ constexpr int colpos(int t, int NT) { return NT * (t & 15) + (t >> 4); }
+__host__ __device__ constexpr int collog(int p, int NT) { return kTile * (p % NT) + p / NT; }
+
 #define TRMF_HIP_CHECK(expr)                                                                  \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

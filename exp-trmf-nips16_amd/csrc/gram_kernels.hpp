@@ -131,63 +131,101 @@ template <int NT> struct GramState {
     }
 };
 
+template <int N> struct alignas(sizeof(real)) RealVec { real v[N]; };
+
+// value of lane (quad base + SRC) of the caller's quad: one VALU DPP mov, no LDS
+template <int SRC> __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55 * SRC, 0xf, 0xf, true);
+}
+template <int SRC> __device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x55 * SRC, 0xf, 0xf, true));
+}
+template <int SRC> __device__ __forceinline__ double quad_bcast(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), 0x55 * SRC, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0x55 * SRC, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // next(desc): advance a wave-uniform descriptor to the following iteration of the stream.
 // row_done(row): called between iterations when the stream leaves `row` (st holds its Gram/rhs/loss).
+//
+// Loads per iteration (4 groups = 16 entries): ONE idx load + ONE val load (lane (g,c) fetches entry
+// e0 + (c&3)*estride + g; group u then takes its entry from quad lane u with a DPP quad_perm
+// broadcast) and FOUR vector loads of the gathered factor rows (column-interleaved layout: the NT
+// slices of a lane are contiguous).
 template <int NT, int D, bool DO_MMA, bool WITH_LOSS, typename Next, typename RowDone>
 __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__restrict__ idx,
                                           const real *__restrict__ val, const real *__restrict__ X,
                                           uint32_t zero_row, uint32_t estride, int lane,
                                           const real (&wq)[NT], GramDesc d0, Next &&next,
                                           RowDone &&row_done) {
+    static_assert(D == 4, "one quad lane per group of the iteration");
     constexpr int KP = kTile * NT;
     const uint32_t g = (uint32_t)(lane >> 4), c = (uint32_t)(lane & 15);
-    uint32_t jA[D]; real yA[D]; bool vA[D];
+    uint32_t jraw; real yraw; bool vraw;                 // entries of iteration n+2 (as loaded)
+    uint32_t jsel; real ysel;                            // entries of iteration n+1 (masked)
     real x[D][NT], yx[D];
 
-    auto load_entries = [&](const GramDesc &d, auto U) {
-        constexpr int u = decltype(U)::value;
-        const uint32_t p = d.e0 + (uint32_t)u * estride + g;
-        vA[u] = p < d.end;
-        const uint32_t pc = vA[u] ? p : 0u;              // clamped: never reads out of bounds
-        jA[u] = idx[pc];
-        yA[u] = val[pc];
+    auto load_entries = [&](const GramDesc &d) {
+        const uint32_t p = d.e0 + (c & 3u) * estride + g;
+        vraw = p < d.end;
+        const uint32_t pc = vraw ? p : 0u;               // clamped: never reads out of bounds
+        jraw = idx[pc];
+        yraw = val[pc];
     };
-    auto load_slices = [&](auto U) {                     // promote slot u: entries -> factor slices
+    auto promote_entries = [&]() {                       // consumes loads issued one iteration ago
+        jsel = vraw ? jraw : zero_row;
+        ysel = vraw ? yraw : real(0);
+    };
+    auto load_slices = [&](auto U) {                     // slot u <- factor row of group u of (jsel, ysel)
         constexpr int u = decltype(U)::value;
-        const uint32_t j = vA[u] ? jA[u] : zero_row;
-        yx[u] = vA[u] ? yA[u] : real(0);
-        const real *src = X + (size_t)j * KP + c;
+        const uint32_t j = quad_bcast<u>(jsel);
+        yx[u] = quad_bcast<u>(ysel);
+        const RealVec<NT> v = *reinterpret_cast<const RealVec<NT> *>(X + (size_t)j * KP + NT * c);
 #pragma unroll
-        for (int q = 0; q < NT; q++) x[u][q] = src[kTile * q];
+        for (int q = 0; q < NT; q++) x[u][q] = v.v[q];
     };
 
     GramDesc d1 = d0; next(d1);
     GramDesc d2 = d1; next(d2);
-    static_for<D>([&](auto U) { load_entries(d0, U); });
-    static_for<D>([&](auto U) { load_slices(U); load_entries(d1, U); });
+    load_entries(d0);
+    promote_entries();
+    static_for<D>([&](auto U) { load_slices(U); });
+    load_entries(d1);
+    real xc[D][NT], yc[D];                               // operands of the iteration being consumed
     while (d0.row >= 0) {
-        // ---- single basic block: consume iteration d0, fetch slices of d1, entries of d2 ----
+        // ---- single basic block ----
+        // top: everything iteration n+1 / n+2 needs is requested first, so each load has a full
+        // iteration of MFMA time (>= 24 x 32 cycles) to land before it is consumed
+#pragma unroll
+        for (int u = 0; u < D; u++) {
+            yc[u] = yx[u];
+#pragma unroll
+            for (int q = 0; q < NT; q++) xc[u][q] = x[u][q];
+        }
+        promote_entries();                               // entries of n+1 (loaded one iteration ago)
+        static_for<D>([&](auto U) { load_slices(U); });  // slices of n+1 -> x / yx
+        load_entries(d2);                                // entries of n+2
         static_for<D>([&](auto U) {
             constexpr int u = decltype(U)::value;
 #pragma unroll
-            for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
+            for (int q = 0; q < NT; q++) st.b[q] = fma(yc[u], xc[u][q], st.b[q]);
             if (DO_MMA) {
                 int t = 0;
 #pragma unroll
                 for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(x[u][ti], x[u][tj], st.acc[t]);
+                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(xc[u][ti], xc[u][tj], st.acc[t]);
             }
             if (WITH_LOSS) {
                 real d = 0;
 #pragma unroll
-                for (int q = 0; q < NT; q++) d = fma(wq[q], x[u][q], d);
+                for (int q = 0; q < NT; q++) d = fma(wq[q], xc[u][q], d);
                 d = row16_sum(d);
-                const real res = yx[u] - d;               // trmf.cpp:238 (val_type arithmetic)
+                const real res = yc[u] - d;               // trmf.cpp:238 (val_type arithmetic)
                 st.loss += (double)res * (double)res;     // masked lanes: y = 0, x = 0 -> 0
             }
-            load_slices(U);
-            load_entries(d2, U);
         });
         // ---- between iterations ----
         if (d1.row != d0.row) { row_done(d0.row); }
@@ -302,7 +340,7 @@ __global__ __launch_bounds__(256) void fsolve_kernel(const uint32_t *__restrict_
             bz = fma(-a[t], xt, bz);        // lanes >= t hold dead values from here on
         }
     }
-    if (lane < k) F[(size_t)row * KP + lane] = x;
+    if (lane < k) F[(size_t)row * KP + colpos(lane, NT)] = x;
 }
 
 #if defined(TRMF_F32)
@@ -334,6 +372,57 @@ template <int NT> __device__ __forceinline__ constexpr int quad_slab_col_offset(
     return n;
 }
 
+// Four right-looking Cholesky factorisations side by side (one per 16-lane row), forward substitution
+// fused, then the row-oriented back substitution.  areg[q][s] = A[s][16q+c] (+lambda on the diagonal,
+// unit diagonal on pad rows so that no k-guard is needed), bz[q] = b[16q+c]; returns x[q] = x[16q+c].
+template <int NT, int KMAX, int ABL = 0>
+__device__ __forceinline__ void quad_factor_solve(float (&areg)[NT][KMAX], float (&bz)[NT], float (&x)[NT], int c) {
+    float dinv[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) dinv[q] = 0;
+    if constexpr (!(ABL & 2))
+    static_for<KMAX>([&](auto J) {
+        constexpr int j = decltype(J)::value, qj = j >> 4, cj = j & 15;
+        {   // one straight-line block: the scheduler can software-pipeline across steps
+            const float inv = inv_sqrt(row_bcast<cj>(areg[qj][j]));
+            float u[NT];
+#pragma unroll
+            for (int q = qj; q < NT; q++) {
+                u[q] = areg[q][j] * inv;
+                if (q == qj && c <= cj) u[q] = 0;       // row j of U, strictly right of the diagonal
+                areg[q][j] = u[q];
+            }
+            const float zj = row_bcast<cj>(bz[qj]) * inv;
+#pragma unroll
+            for (int q = qj; q < NT; q++) bz[q] = fmaf(-u[q], zj, bz[q]);
+            if (c == cj) { bz[qj] = zj; dinv[qj] = inv; }
+            static_for<KMAX>([&](auto Sx) {
+                constexpr int s = decltype(Sx)::value, qs = s >> 4, cs = s & 15;
+                if constexpr (s > j) {
+                    const float us = row_bcast<cs>(u[qs]);
+#pragma unroll
+                    for (int q = qs; q < NT; q++) areg[q][s] = fmaf(-us, u[q], areg[q][s]);
+                }
+            });
+        }
+    });
+    // back substitution U x = z, row-oriented, reduction inside the 16-lane row (DPP)
+#pragma unroll
+    for (int q = 0; q < NT; q++) x[q] = 0;
+    if constexpr (!(ABL & 4))
+    static_for<KMAX>([&](auto Jr) {
+        constexpr int j = KMAX - 1 - decltype(Jr)::value, qj = j >> 4, cj = j & 15;
+        {
+            float part = 0;
+#pragma unroll
+            for (int q = qj; q < NT; q++) part = fmaf(areg[q][j], x[q], part);
+            const float sum = row16_allsum_dpp(part);
+            const float xv = (bz[qj] - sum) * dinv[qj];
+            if (c == cj) x[qj] = xv;
+        }
+    });
+}
+
 // Stream over the (up to) four rows of a quad: each row padded to a multiple of D groups.
 struct QuadStream {
     uint32_t pr[5];   // CSR pointers of the quad's rows (wave-uniform)
@@ -359,8 +448,12 @@ struct QuadStream {
 };
 
 // ABL: compile-time ablation mask for profiling (bit0 skip Gram, bit1 skip factorisation, bit2 skip back solve)
+// 3 wavefronts per SIMD (<= 168 VGPRs): measured 551 -> 481 us at config 3 versus the unconstrained 192
+#ifndef TRMF_QUAD_WAVES
+#define TRMF_QUAD_WAVES 3
+#endif
 template <int NT, int KMAX, int ABL = 0>
-__global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
+__global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,
                                                           const float *__restrict__ val,
                                                           const float *__restrict__ X,
@@ -451,59 +544,202 @@ __global__ __launch_bounds__(256) void fsolve_quad_kernel(const uint32_t *__rest
                                                finalize);
     }
 
-    // ---- four right-looking Cholesky factorisations side by side, forward substitution fused ----
-    float dinv[NT];
-#pragma unroll
-    for (int q = 0; q < NT; q++) dinv[q] = 0;
-    if constexpr (!(ABL & 2))
-    static_for<KMAX>([&](auto J) {
-        constexpr int j = decltype(J)::value, qj = j >> 4, cj = j & 15;
-        {   // no k-guard: rows >= k are identity rows (see finalize), so the whole factorisation is
-            // one straight-line block the scheduler can software-pipeline
-            const float inv = inv_sqrt(row_bcast<cj>(areg[qj][j]));
-            float u[NT];
-#pragma unroll
-            for (int q = qj; q < NT; q++) {
-                u[q] = areg[q][j] * inv;
-                if (q == qj && c <= cj) u[q] = 0;       // row j of U, strictly right of the diagonal
-                areg[q][j] = u[q];
-            }
-            const float zj = row_bcast<cj>(bz[qj]) * inv;
-#pragma unroll
-            for (int q = qj; q < NT; q++) bz[q] = fmaf(-u[q], zj, bz[q]);
-            if (c == cj) { bz[qj] = zj; dinv[qj] = inv; }
-            static_for<KMAX>([&](auto Sx) {
-                constexpr int s = decltype(Sx)::value, qs = s >> 4, cs = s & 15;
-                if constexpr (s > j) {
-                    const float us = row_bcast<cs>(u[qs]);
-#pragma unroll
-                    for (int q = qs; q < NT; q++) areg[q][s] = fmaf(-us, u[q], areg[q][s]);
-                }
-            });
-        }
-    });
-
-    // ---- back substitution U x = z, row-oriented, reduction inside the 16-lane row ----
     float x[NT];
+    quad_factor_solve<NT, KMAX, ABL>(areg, bz, x, c);
+    if (mine) {     // logical columns {c, 16+c, ...} are adjacent in the interleaved layout: one vector store
+        RealVec<NT> o;
 #pragma unroll
-    for (int q = 0; q < NT; q++) x[q] = 0;
-    if constexpr (!(ABL & 4))
-    static_for<KMAX>([&](auto Jr) {
-        constexpr int j = KMAX - 1 - decltype(Jr)::value, qj = j >> 4, cj = j & 15;
-        {
-            float part = 0;
-#pragma unroll
-            for (int q = qj; q < NT; q++) part = fmaf(areg[q][j], x[q], part);
-            const float sum = row16_allsum_dpp(part);
-            const float xv = (bz[qj] - sum) * dinv[qj];
-            if (c == cj) x[qj] = xv;
-        }
-    });
-    if (mine) {
-#pragma unroll
-        for (int q = 0; q < NT; q++)
-            if (kTile * q + c < k) F[(size_t)(row0 + grp) * KP + kTile * q + c] = x[q];
+        for (int q = 0; q < NT; q++) o.v[q] = (kTile * q + c < k) ? x[q] : 0.0f;
+        *reinterpret_cast<RealVec<NT> *>(F + (size_t)(row0 + grp) * KP + NT * c) = o;
     }
+}
+
+// ---- F-solve, producer/consumer form (fp32) -----------------------------------------------------------
+// PMC of the quad kernel: MFMA pipe busy 37 %, VALU busy 40 %, but at 192 registers only two wavefronts
+// fit a SIMD and their matrix and vector phases rarely overlap.  Here a workgroup is TWO wavefronts
+// with different jobs and <= 128 registers each (4 wavefronts per SIMD):
+//   wave 0, producer: one gram_ring() stream over the workgroup's rows (MFMA + gathers); every finished
+//           Gram (+lambda) and rhs goes into one of kPcSlabs LDS slabs;
+//   wave 1, consumer: pulls each slab into the registers of one 16-lane row and, every four systems,
+//           runs quad_factor_solve() (VALU + ds_swizzle/DPP) and stores four rows of F.
+// Hand-off through two LDS counters (full / drained) with plain polling: the producer may run
+// kPcSlabs rows ahead, so neither side waits in steady state.  Every spin is bounded; on timeout the
+// workgroup raises *err (checked by the host) instead of hanging the device.
+constexpr int kPcSlabs = 2;
+constexpr int kPcRows = 16;         // item rows per workgroup
+constexpr int kPcSpinLimit = 1 << 22;
+#ifndef TRMF_PC_ROLE_SHIFT
+#define TRMF_PC_ROLE_SHIFT 1
+#endif
+constexpr int kPcRoleShift = TRMF_PC_ROLE_SHIFT;
+
+__device__ __forceinline__ bool pc_wait_ge(volatile int *cnt, int target, volatile int *abort_flag) {
+    int spins = 0;
+    while (*cnt < target) {
+        __builtin_amdgcn_s_sleep(4);
+        if (*abort_flag) return false;
+        if (++spins > kPcSpinLimit) { *abort_flag = 1; return false; }
+    }
+    return true;
+}
+
+// Stream over the non-empty rows among [r_lo, r_hi): row pointers come from LDS (sptr[i] = ptr[r_lo+i]).
+struct ChunkStream {
+    const volatile uint32_t *sptr;
+    int nrows;
+    uint32_t step;
+    __device__ __forceinline__ uint32_t at(int i) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)sptr[i]); }
+    __device__ __forceinline__ GramDesc first() const {
+        for (int r = 0; r < nrows; r++)
+            if (at(r + 1) > at(r)) return GramDesc{at(r), at(r + 1), r};
+        return GramDesc{0, 0, -1};
+    }
+    __device__ __forceinline__ void operator()(GramDesc &d) const {
+        if (d.row < 0) return;
+        d.e0 += step;
+        if (d.e0 < d.end) return;
+        int r = d.row + 1;
+        while (r < nrows && at(r + 1) == at(r)) r++;                   // skip empty rows (trmf.cpp:374)
+        if (r < nrows) d = GramDesc{at(r), at(r + 1), r};
+        else d = GramDesc{0, 0, -1};
+    }
+};
+
+template <int NT, int KMAX, int ABL = 0>
+__global__ __launch_bounds__(128, 4) void fsolve_pc_kernel(const uint32_t *__restrict__ ptr,
+                                                           const uint32_t *__restrict__ idx,
+                                                           const float *__restrict__ val,
+                                                           const float *__restrict__ X,
+                                                           float *__restrict__ F, uint32_t row_begin,
+                                                           uint32_t row_end, int k, float lambda,
+                                                           uint32_t zero_row, int *__restrict__ err) {
+    static_assert(sizeof(real) == 4, "producer/consumer F-solve is the fp32 path");
+    constexpr int KP = kTile * NT;
+    constexpr int SLABF = quad_slab_floats<NT>() + KP;               // Gram columns + rhs
+    __shared__ __attribute__((aligned(16))) float lds_slab[kPcSlabs][SLABF];
+    __shared__ uint32_t lds_ptr[kPcRows + 1];
+    __shared__ int lds_cnt[3];                                          // full, drained, abort
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, c = lane & 15;
+    const uint32_t r_lo = row_begin + blockIdx.x * (uint32_t)kPcRows;
+    if (r_lo >= row_end) return;
+    const int nrows = (int)min((uint32_t)kPcRows, row_end - r_lo);
+    if ((int)threadIdx.x <= nrows) lds_ptr[threadIdx.x] = ptr[r_lo + threadIdx.x];
+    if (threadIdx.x < 3) lds_cnt[threadIdx.x] = 0;
+    __syncthreads();                                                    // the only workgroup barrier
+    volatile int *full_cnt = &lds_cnt[0], *drain_cnt = &lds_cnt[1], *abort_flag = &lds_cnt[2];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+
+    // Role assignment.  The dispatcher was observed to put wave 0 of successive 2-wave workgroups on
+    // SIMDs {0,1} and wave 1 on SIMDs {2,3}; a fixed wave->role map would then run every producer on
+    // two matrix pipes and every consumer on two VALUs (measured: 2x slower).  Alternating the roles
+    // with the workgroup index spreads both over all four SIMDs (speed only, never correctness).
+    const int swap = (int)((blockIdx.x >> kPcRoleShift) & 1u);
+#if defined(TRMF_PC_DEBUG)
+    if (lane == 0) {   // histogram of (role, SIMD) from HW_REG_HW_ID[5:4]
+        const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+        atomicAdd(&err[1 + (wave ^ swap) * 4 + simd], 1);
+    }
+#endif
+    if ((wave ^ swap) == 0) {
+        // ------------------------------------------------ producer ------------------------------------------------
+        GramState<NT> st;
+        st.clear();
+        int produced = 0;
+        ChunkStream stream{lds_ptr, nrows, 4u * kRingDepth};
+        auto publish = [&](int /*row*/) {
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                st.b[q] += __shfl_xor(st.b[q], 16, kWave);
+                st.b[q] += __shfl_xor(st.b[q], 32, kWave);
+            }
+            if (!pc_wait_ge(drain_cnt, produced - kPcSlabs + 1, abort_flag)) { st.clear(); return; }
+            float *S = lds_slab[produced % kPcSlabs];
+            int t = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+                for (int tj = ti; tj < NT; tj++, t++) {
+                    f4 v = st.acc[t];
+                    if (ti == tj) {
+#pragma unroll
+                        for (int r = 0; r < 4; r++)   // + lambda (trmf.cpp:393); pad rows: unit diagonal
+                            if (c == 4 * grp + r) v[r] += (kTile * ti + c < k) ? lambda : 1.0f;
+                    }
+                    *reinterpret_cast<f4 *>(&S[quad_slab_col_offset<NT>(tj) + c * (kTile * (tj + 1) + 4) + kTile * ti + 4 * grp]) = v;
+                }
+            if (grp == 0) {
+#pragma unroll
+                for (int q = 0; q < NT; q++) S[quad_slab_floats<NT>() + kTile * q + c] = st.b[q];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            produced++;
+            if (lane == 0) *full_cnt = produced;
+            st.clear();
+        };
+        float nowq[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) nowq[q] = 0;
+        gram_ring<NT, kRingDepth, !(ABL & 1), false>(st, idx, val, X, zero_row, 4u, lane, nowq, stream.first(), stream, publish);
+    } else {
+        // ------------------------------------------------ consumer ------------------------------------------------
+        float areg[NT][KMAX];
+        float bz[NT];
+        auto reset = [&]() {
+#pragma unroll
+            for (int q = 0; q < NT; q++) {
+                bz[q] = 0;
+#pragma unroll
+                for (int s = 0; s < KMAX; s++) areg[q][s] = (s == kTile * q + c) ? 1.0f : 0.0f;   // idle rows: identity
+            }
+        };
+        reset();
+        int consumed = 0;
+        uint32_t myrow = 0;
+        bool mine = false;
+        for (int r = 0; r < nrows; r++) {
+            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ptr[r]);
+            const uint32_t a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ptr[r + 1]);
+            const bool last = (r == nrows - 1);
+            if (a1 > a0) {
+                if (!pc_wait_ge(full_cnt, consumed + 1, abort_flag)) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const float *S = lds_slab[consumed % kPcSlabs];
+                if (grp == (consumed & 3)) {
+                    mine = true;
+                    myrow = r_lo + (uint32_t)r;
+#pragma unroll
+                    for (int q = 0; q < NT; q++) {
+                        bz[q] = S[quad_slab_floats<NT>() + kTile * q + c];
+#pragma unroll
+                        for (int s4 = 0; s4 < KMAX / 4; s4++) {
+                            if (4 * s4 <= kTile * q + 15) {
+                                const f4 v = *reinterpret_cast<const f4 *>(&S[quad_slab_col_offset<NT>(q) + c * (kTile * (q + 1) + 4) + 4 * s4]);
+                                areg[q][4 * s4 + 0] = v[0]; areg[q][4 * s4 + 1] = v[1];
+                                areg[q][4 * s4 + 2] = v[2]; areg[q][4 * s4 + 3] = v[3];
+                            }
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                consumed++;
+                if (lane == 0) *drain_cnt = consumed;
+            }
+            if (consumed > 0 && ((consumed & 3) == 0 || last) && __builtin_amdgcn_readfirstlane((int)__any(mine))) {
+                float x[NT];
+                quad_factor_solve<NT, KMAX, (ABL & 2) ? 6 : 0>(areg, bz, x, c);
+                if (mine) {
+                    RealVec<NT> o;
+#pragma unroll
+                    for (int q = 0; q < NT; q++) o.v[q] = (kTile * q + c < k) ? x[q] : 0.0f;
+                    *reinterpret_cast<RealVec<NT> *>(F + (size_t)myrow * KP + NT * c) = o;
+                }
+                mine = false;
+                reset();
+            }
+        }
+    }
+    if (lane == 0 && *abort_flag) *err = 1;
 }
 #endif  // TRMF_F32
 
@@ -532,7 +768,7 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
     st.clear();
     real wq[NT];
 #pragma unroll
-    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + kTile * q + c];
+    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + NT * c + q];
     {   // this wavefront takes groups wave, wave+4, ... of the row
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p0 + 4u * (uint32_t)wave));
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
@@ -601,7 +837,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const uint32_t *__restrict__ 
     st.clear();
     real wq[NT];
 #pragma unroll
-    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + kTile * q + c];
+    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + NT * c + q];
     {
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p0 + 4u * (uint32_t)wave));
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);

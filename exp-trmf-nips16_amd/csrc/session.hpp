@@ -99,13 +99,15 @@ struct TrmfSessionImpl {
     // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).
     int upload_padded(DevBuf<real> &dst, const real *src, size_t rows) {
         std::vector<real> tmp((rows + 1) * (size_t)KP, real(0));
-        for (size_t i = 0; i < rows; i++) std::memcpy(&tmp[i * KP], src + i * (size_t)k, sizeof(real) * k);
+        for (size_t i = 0; i < rows; i++)
+            for (int t = 0; t < k; t++) tmp[i * KP + colpos(t, NT)] = src[i * (size_t)k + t];   // interleaved columns
         return dst.upload(tmp.data(), tmp.size());
     }
     int download_padded(const DevBuf<real> &src, real *dst, size_t rows) {
         std::vector<real> tmp(rows * (size_t)KP);
         if (tmp.size()) TRMF_HIP_CHECK(hipMemcpy(tmp.data(), src.p, tmp.size() * sizeof(real), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < rows; i++) std::memcpy(dst + i * (size_t)k, &tmp[i * KP], sizeof(real) * k);
+        for (size_t i = 0; i < rows; i++)
+            for (int t = 0; t < k; t++) dst[i * (size_t)k + t] = tmp[i * KP + colpos(t, NT)];
         return 0;
     }
     static int upload_ptr32(DevBuf<uint32_t> &dst, const size_t *src, size_t count) {
@@ -120,7 +122,12 @@ struct TrmfSessionImpl {
         KP = padded_rank(k); NT = KP / kTile; KMAX = ((k + 7) / 8) * 8;
         nlag = (int)lag_size; midx = nlag ? (int)lags[nlag - 1] : 0;
         comm = active_comm();
-        if (const char *e = getenv("TRMF_FSOLVE")) use_quad = use_quad && std::string(e) != "wave";
+        if (const char *e = getenv("TRMF_FSOLVE")) {
+            const std::string m(e);
+            use_quad = use_quad && m != "wave";
+            use_pc = sizeof(real) == 4 && m == "pc";
+        }
+        if (dev_err.alloc(16)) return kFail;
         if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
         host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -156,7 +163,7 @@ struct TrmfSessionImpl {
                 nbt = std::min(kMaxPartials, (T + TI - 1) / TI);
             }
         }
-        xp.T = T; xp.k = k; xp.KP = KP; xp.nlag = nlag; xp.midx = midx;
+        xp.T = T; xp.k = k; xp.KP = KP; xp.NT = NT; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
 
         fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1);
@@ -213,13 +220,52 @@ struct TrmfSessionImpl {
 #endif
         return 0;
     }
-    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64 or TRMF_FSOLVE=wave: one per wavefront
+    template <int NT_, int KMAX_> int launch_fsolve_pc(uint32_t rb, uint32_t re) {
+        const uint32_t rows = re - rb;
+        if (rows == 0) return 0;
+#if defined(TRMF_F32)
+        const dim3 grid((rows + kPcRows - 1) / kPcRows), block(128);
+#define TRMF_LAUNCH_PC(ABL)                                                                            \
+        hipLaunchKernelGGL((fsolve_pc_kernel<NT_, KMAX_, ABL>), grid, block, 0, stream, Yc_ptr.p,      \
+                           Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T, dev_err.p)
+#if defined(TRMF_ABLATION)
+        if (NT_ == 3 && KMAX_ == 40 && dbg_flags) {
+            switch (dbg_flags) {
+                case 1: TRMF_LAUNCH_PC(1); break;
+                case 2: TRMF_LAUNCH_PC(2); break;
+                default: TRMF_LAUNCH_PC(3); break;
+            }
+            return 0;
+        }
+#endif
+        TRMF_LAUNCH_PC(0);
+#undef TRMF_LAUNCH_PC
+#endif
+        return 0;
+    }
+    // fp32: four systems per wavefront (fsolve_quad_kernel).  TRMF_FSOLVE=pc selects the experimental
+    // producer/consumer wavefront pairs (correct, currently slower: DESIGN.md 4.2); fp64 or
+    // TRMF_FSOLVE=wave: one system per wavefront
     bool use_quad = sizeof(real) == 4;
+    bool use_pc = false;
+    DevBuf<int> dev_err;
     int dbg_flags = 0;           // TRMF_DEBUG_ABLATE: bit0 skip Gram, bit1 skip factorisation, bit2 skip back-solve
     int fsolve(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
-        if (use_quad) {
+        if (use_pc) {
+            switch (KMAX) {
+                case 8:  launch_fsolve_pc<1, 8>(rb, re); break;
+                case 16: launch_fsolve_pc<1, 16>(rb, re); break;
+                case 24: launch_fsolve_pc<2, 24>(rb, re); break;
+                case 32: launch_fsolve_pc<2, 32>(rb, re); break;
+                case 40: launch_fsolve_pc<3, 40>(rb, re); break;
+                case 48: launch_fsolve_pc<3, 48>(rb, re); break;
+                case 56: launch_fsolve_pc<4, 56>(rb, re); break;
+                case 64: launch_fsolve_pc<4, 64>(rb, re); break;
+                default: set_error("unsupported rank"); return kFail;
+            }
+        } else if (use_quad) {
             switch (KMAX) {
                 case 8:  launch_fsolve_quad<1, 8>(rb, re); break;
                 case 16: launch_fsolve_quad<1, 16>(rb, re); break;
@@ -426,7 +472,20 @@ struct TrmfSessionImpl {
         return 0;
     }
 
-    int sync() { TRMF_HIP_CHECK(hipStreamSynchronize(stream)); return 0; }
+    int sync() {
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        int e = 0;
+        TRMF_HIP_CHECK(hipMemcpy(&e, dev_err.p, sizeof(int), hipMemcpyDeviceToHost));
+#if defined(TRMF_PC_DEBUG)
+        {
+            int h[16];
+            TRMF_HIP_CHECK(hipMemcpy(h, dev_err.p, sizeof h, hipMemcpyDeviceToHost));
+            fprintf(stderr, "pc placement: producer simd[0..3] = %d %d %d %d ; consumer = %d %d %d %d\n", h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+        }
+#endif
+        if (e) { set_error("F-solve producer/consumer hand-off timed out (device error flag set)"); return kFail; }
+        return 0;
+    }
 
     int stats(TrmfIterStats *out, int cap) {
         if (sync()) return kFail;

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void theta_gram_kernel(const real *__restrict_
     const int i0 = midx + ch * kThetaChunk;
     const int i1 = min(T, i0 + kThetaChunk);
     const int lo = i0 - midx;                           // first timestamp staged
-    for (int i = lo + threadIdx.x; i < i1; i += 256) series[i - lo] = W[(size_t)i * KP + t];
+    const int tp = colpos(t, KP / kTile);                 // column-interleaved factor layout
+    for (int i = lo + threadIdx.x; i < i1; i += 256) series[i - lo] = W[(size_t)i * KP + tp];
     __syncthreads();
     for (int p = threadIdx.x; p < npairs; p += 256) {
         int a, b; bool rhs;
