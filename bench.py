@@ -184,6 +184,13 @@ def main():
     if rank == 0:
         nnz = int(prob['Y'].nnz)
         achieved = bytes_f / (ms_fk * 1e-3) / 1e9 if ms_fk > 0 else 0.0
+        traffic = None      # HBM bytes per launch from the committed PMC profile of this config (1 GPU only)
+        try:
+            tj = json.load(open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')))
+            if tj.get('config') == args.config and world == 1:
+                traffic = tj['traffic_bytes']
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             'metric': 'als_iterations_per_sec', 'value': args.steps / elapsed, 'unit': 'iter/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -195,7 +202,7 @@ def main():
                 hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
                 'parallelism': 'F rows / X-Gram rows sharded x{}, CG replicated'.format(world)},
             'roofline': {'kernel': 'fsolve_quad_kernel<3,40>' if dtype == np.float32 else 'fsolve_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
                          'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows'},
             'phases_ms': {'F': float(np.mean([x['ms_F'] for x in st])), 'X': float(np.mean([x['ms_X'] for x in st])),

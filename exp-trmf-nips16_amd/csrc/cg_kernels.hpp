@@ -32,24 +32,46 @@ struct XParams {
     double lambdaI, lambdaAR, eps_cg;
 };
 
-// Fixed-order block reduction (blockDim.x == 256). Result valid in every thread.
-__device__ __forceinline__ double block_allsum(double v, double *smem /* >= 256 */) {
-    smem[threadIdx.x] = v;
-    __syncthreads();
+// Fixed-order block reductions (blockDim.x == 256 = 4 wavefronts).  Butterfly inside the wavefront
+// (no barrier), then the four wave sums are combined in a fixed order: deterministic, identical in
+// every thread, two barriers instead of a nine-barrier LDS tree.
+__device__ __forceinline__ double wave_butterfly_sum(double v) {
 #pragma unroll
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) smem[threadIdx.x] += smem[threadIdx.x + off];
-        __syncthreads();
-    }
-    const double r = smem[0];
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double block_allsum(double v, double *smem /* >= 16 doubles */) {
+    v = wave_butterfly_sum(v);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
     __syncthreads();
     return r;
+}
+// three sums sharing the barriers
+__device__ __forceinline__ void block_allsum3(double &a, double &b, double &c, double *smem) {
+    a = wave_butterfly_sum(a); b = wave_butterfly_sum(b); c = wave_butterfly_sum(c);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smem[w] = a; smem[4 + w] = b; smem[8 + w] = c; }
+    __syncthreads();
+    a = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    b = (smem[4] + smem[5]) + (smem[6] + smem[7]);
+    c = (smem[8] + smem[9]) + (smem[10] + smem[11]);
+    __syncthreads();
 }
 // Sum of a partial array written by a producer kernel with `np` blocks; identical in every block.
 __device__ __forceinline__ double sum_partials(const double *__restrict__ P, int np, double *smem) {
     double v = 0;
     for (int i = threadIdx.x; i < np; i += 256) v += P[i];
     return block_allsum(v, smem);
+}
+// two partial arrays of the same length in one pass
+__device__ __forceinline__ void sum_partials2(const double *__restrict__ P, const double *__restrict__ Q, int np,
+                                              double &sp, double &sq, double *smem) {
+    double a = 0, b = 0, c = 0;
+    for (int i = threadIdx.x; i < np; i += 256) { a += P[i]; b += Q[i]; }
+    block_allsum3(a, b, c, smem);
+    sp = a; sq = b;
 }
 __device__ __forceinline__ bool cg_stopped(real rho, real cgtol) {           // rf_tron.h:444-446
     return sqrt((double)rho) <= (double)cgtol;
@@ -234,12 +256,16 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
     __shared__ double smem[256];
     real tmp = 0;
     if (Prr_cur != nullptr) {
-        const real rho = (real)sum_partials(Prr_cur, np, smem);
-        if (cg_stopped(rho, st->cgtol)) return;
         if (FUSE_DIR) {
-            const real rho_prev = (real)sum_partials(Prr_prev, np, smem);
+            double s_cur, s_prev;
+            sum_partials2(Prr_cur, Prr_prev, np, s_cur, s_prev, smem);
+            const real rho = (real)s_cur, rho_prev = (real)s_prev;
+            if (cg_stopped(rho, st->cgtol)) return;
             const real beta = rho / rho_prev;                                // rf_tron.h:495
             tmp = beta - (real)1.0;                                          // rf_tron.h:497
+        } else {
+            const real rho = (real)sum_partials(Prr_cur, np, smem);
+            if (cg_stopped(rho, st->cgtol)) return;
         }
     }
     const int k = p.k, KP = p.KP, T = p.T, Hh = p.midx, nlag = p.nlag;
@@ -298,8 +324,14 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
                 const real *Gi = G + (size_t)i * k * k + t;
                 const real *vi = vs + (rr + Hh) * KP;
                 double acc = 0;
+// logical column s2 = 16q + c sits at position NT*c + q: two constant-stride loops
+                for (int q = 0; q < p.NT; q++) {
+                    const int cn = min(kTile, k - kTile * q);
+                    const real *Gq = Gi + (size_t)(kTile * q) * k;
+                    const real *vq = vi + q;
 #pragma unroll 8
-                for (int s2 = 0; s2 < k; s2++) acc += (double)Gi[(size_t)s2 * k] * (double)vi[colpos(s2, p.NT)];
+                    for (int c2 = 0; c2 < cn; c2++) acc += (double)Gq[(size_t)c2 * k] * (double)vq[c2 * p.NT];
+                }
                 real o;
                 if (p.lambdaI == 0) o = 0;
                 else if (p.lambdaI == 1) o = x;
@@ -319,9 +351,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
             }
         }
     }
-    ar2 = block_allsum(ar2, smem);
-    vv = block_allsum(vv, smem);
-    dot = block_allsum(dot, smem);
+    block_allsum3(ar2, vv, dot, smem);
     if (threadIdx.x == 0) {
         Pbase[P_AR * kMaxPartials + blockIdx.x] = ar2;
         Pbase[P_VV * kMaxPartials + blockIdx.x] = vv;
@@ -371,12 +401,16 @@ __global__ __launch_bounds__(256) void cg_update_kernel(XParams p, XState *__res
                                                         const real *__restrict__ Hd,
                                                         real *__restrict__ s, real *__restrict__ r) {
     __shared__ double smem[256];
-    const real rho = (real)sum_partials(Prr_cur, np, smem);
+    double s_rho = 0, s_dHd = 0, s_unused = 0;
+    for (int i = threadIdx.x; i < np; i += 256) s_rho += Prr_cur[i];
+    for (int i = threadIdx.x; i < np_dHd; i += 256) s_dHd += PdHd[i];
+    block_allsum3(s_rho, s_dHd, s_unused, smem);
+    const real rho = (real)s_rho;
     if (cg_stopped(rho, st->cgtol)) {
         if (threadIdx.x == 0) Prr_next[blockIdx.x] = Prr_cur[blockIdx.x];
         return;
     }
-    const real dHd = (real)sum_partials(PdHd, np_dHd, smem);
+    const real dHd = (real)s_dHd;
     const real alpha = rho / dHd;                                            // rf_tron.h:460
     const real nalpha = -alpha;
     const size_t N = (size_t)p.T * p.KP;
