@@ -25,11 +25,16 @@ struct XState {
 };
 
 // partial-sum arrays: Pbase[slot * kMaxPartials + block]
-enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_NSLOTS = 7 };
+enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_LQ = 7, P_NSLOTS = 8 };
 
 struct XParams {
     int T, k, KP, NT, nlag, midx;      // NT = KP/16: vectors use the column-interleaved layout (colpos)
     double lambdaI, lambdaAR, eps_cg;
+    // full-observation path (missing == 0, trmf.cpp:155-215): one shared Gram H^T H for every
+    // timestamp (gstride == 0) and fun = base + 0.5*(tr Y^T Y + sum_i w_i^T G w_i - 2 b_i.w_i)
+    int full;
+    size_t gstride;                    // elements between consecutive per-timestamp Grams (k*k or 0)
+    double trYTY;
 };
 
 // Fixed-order block reductions (blockDim.x == 256 = 4 wavefronts).  Butterfly inside the wavefront
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;     // t: logical column
     const int tp = colpos(t, p.NT);                                 // its position in a vector row
     const bool active_lane = lr < rpb;
-    double dot = 0;
+    double dot = 0, lq = 0;
     const int ngroups = (p.T + rpb - 1) / rpb;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int i = grp * rpb + lr;
@@ -211,19 +216,24 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
                 }
             }
             // cached Gram: sum_s G_i[s][t] * v_i[s]
-            const real *Gi = G + (size_t)i * k * k + t;
+            const real *Gi = G + (size_t)i * p.gstride + t;
             const real *vi = vs + lr * k;
             double acc = 0;
 #pragma unroll 8
             for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k] * (double)vi[s];
-            if (minus_b) acc -= (double)Bv[(size_t)i * KP + t];
+            if (minus_b) {
+                const double bb = (double)Bv[(size_t)i * KP + t];
+                lq += (double)x * (acc - 2.0 * bb);                          // w.(Gw) - 2 b.w
+                acc -= bb;
+            }
             o = (real)((double)o + acc);
             out[(size_t)i * KP + tp] = o;
             dot += (double)(dot_mode ? x : o) * (double)o;
         }
     }
     dot = block_allsum(dot, smem);
-    if (threadIdx.x == 0) Pdot[blockIdx.x] = dot;
+    lq = block_allsum(lq, smem);
+    if (threadIdx.x == 0) { Pdot[blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * kMaxPartials + blockIdx.x] = lq; }
 }
 
 // ---- fused Hessian-vector / gradient kernel, tiled over time in LDS --------------------------------
@@ -277,7 +287,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
     for (int e = threadIdx.x; e < nlag * k; e += 256) ths[e] = theta[e];     // Theta(l,t) at ths[t*nlag+l]
     for (int e = threadIdx.x; e < nlag; e += 256) lags[e] = (int)lag_set[e];
     const bool ar_on = nlag > 0 && p.lambdaAR > 0;
-    double ar2 = 0, vv = 0, dot = 0;
+    double ar2 = 0, vv = 0, dot = 0, lq = 0;
     const int ntiles = (T + TI - 1) / TI;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int i0 = tile * TI, i1 = min(i0 + TI, T);
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
             const int rr = r0 + lr, i = i0 + rr;
             if (lr < rpb && rr < TI && i < T) {
                 const real x = vs[(rr + Hh) * KP + tp];
-                const real *Gi = G + (size_t)i * k * k + t;
+                const real *Gi = G + (size_t)i * p.gstride + t;
                 const real *vi = vs + (rr + Hh) * KP;
                 double acc = 0;
 // logical column s2 = 16q + c sits at position NT*c + q: two constant-stride loops
@@ -344,7 +354,11 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
                             o = (real)((double)o - p.lambdaAR * rs[(rr + lags[l]) * KP + tp] * (double)ths[t * nlag + l]);
                     }
                 }
-                if (minus_b) acc -= (double)Bv[(size_t)i * KP + t];
+                if (minus_b) {
+                    const double bb = (double)Bv[(size_t)i * KP + t];
+                    lq += (double)x * (acc - 2.0 * bb);                      // w.(Gw) - 2 b.w
+                    acc -= bb;
+                }
                 o = (real)((double)o + acc);
                 out[(size_t)i * KP + tp] = o;
                 dot += (double)(dot_mode ? x : o) * (double)o;
@@ -352,6 +366,10 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
         }
     }
     block_allsum3(ar2, vv, dot, smem);
+    if (minus_b) {
+        lq = block_allsum(lq, smem);
+        if (threadIdx.x == 0) Pbase[P_LQ * kMaxPartials + blockIdx.x] = lq;
+    }
     if (threadIdx.x == 0) {
         Pbase[P_AR * kMaxPartials + blockIdx.x] = ar2;
         Pbase[P_VV * kMaxPartials + blockIdx.x] = vv;
@@ -369,11 +387,13 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
     const double ar2 = sum_partials(Pbase + P_AR * kMaxPartials, np_base, smem);
     const double vv = sum_partials(Pbase + P_VV * kMaxPartials, np_base, smem);
     const double gg = sum_partials(Pbase + P_DOT * kMaxPartials, np_dot, smem);
+    const double lq = p.full ? sum_partials(Pbase + P_LQ * kMaxPartials, np_dot, smem) : 0.0;
     const real ggr = (real)gg;                                               // BLAS dot in val_type
     // rho[0] = r^T r = g^T g (rf_tron.h:439), published as a one-hot partial array
     if (threadIdx.x == 0) Pbase[P_RR0 * kMaxPartials + blockIdx.x] = (blockIdx.x == 0) ? (double)ggr : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double f = 0.5 * st->loss0;
+        // sparse path: loss0 = sum of squared residuals (gram_x_kernel); full path: trmf.cpp:189-197
+        double f = p.full ? 0.5 * (p.trYTY + lq) : 0.5 * st->loss0;
         if (p.lambdaI > 0) f += 0.5 * p.lambdaI * (double)(real)vv;          // trmf.cpp:73-75
         if (p.nlag > 0 && p.lambdaAR > 0) f += 0.5 * p.lambdaAR * ar2;       // trmf.cpp:94
         const double gnorm = sqrt((double)ggr);

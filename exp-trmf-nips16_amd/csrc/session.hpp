@@ -22,6 +22,7 @@
 #include "../../include/trmf_abi.h"
 #include "cg_kernels.hpp"
 #include "comm.hpp"
+#include "full_kernels.hpp"
 #include "common.hpp"
 #include "gram_kernels.hpp"
 #include "theta_kernels.hpp"
@@ -76,6 +77,13 @@ struct TrmfSessionImpl {
     DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set;
     DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, d0, d1, Hd, w_new;
     DevBuf<double> rAR, lossrow, partials, theta_part;
+    // full-observation path (missing == 0)
+    bool full = false, dense = false;
+    DevBuf<real> Yd_tn, Yd_nt;                // dense Y as T x n and as n x T (both row-major)
+    DevBuf<real> Bf, GSf, GSx;                // F-side right-hand sides (n x KP), shared Grams (k x k)
+    DevBuf<double> gemm_part, sgram_part;
+    double trYTY = 0;
+    static constexpr int kGemmChunks = 32, kSmallGramBlocks = 256;
     DevBuf<XState> xstate;
     DevBuf<DeviceIterLog> log;
     static constexpr int kLogCap = 4096;
@@ -129,22 +137,52 @@ struct TrmfSessionImpl {
         }
         if (dev_err.alloc(16)) return kFail;
         if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
-        host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
+        if (Y->type == TRMF_SPARSE) host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
-        if (upload_ptr32(Yr_ptr, Y->row_ptr, (size_t)T + 1)) return kFail;
-        if (Yr_idx.upload(Y->col_idx, nnz)) return kFail;
-        if (Yr_val.upload((const real *)Y->val_t, nnz)) return kFail;
-        if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
-        if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
-        if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
+        dense = Y->type != TRMF_SPARSE;
+        if (!dense) {
+            if (upload_ptr32(Yr_ptr, Y->row_ptr, (size_t)T + 1)) return kFail;
+            if (Yr_idx.upload(Y->col_idx, nnz)) return kFail;
+            if (Yr_val.upload((const real *)Y->val_t, nnz)) return kFail;
+            if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
+            if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
+            if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
+            if (full) {
+                const real *v = (const real *)Y->val_t;
+                double acc = 0;
+                for (uint64_t e = 0; e < nnz; e++) acc += (double)v[e] * (double)v[e];
+                trYTY = (double)(real)acc;                                   // do_dot_product(Y, Y), trmf.cpp:184
+            }
+        } else {
+            // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC
+            const real *v = (const real *)Y->val;
+            const bool rowmajor = Y->type == TRMF_DENSE_ROWMAJOR;
+            std::vector<real> tn((size_t)T * n), nt((size_t)T * n);
+            double acc = 0;
+            for (int j = 0; j < T; j++)
+                for (int i = 0; i < n; i++) {
+                    const real y = rowmajor ? v[(size_t)j * n + i] : v[(size_t)i * T + j];
+                    tn[(size_t)j * n + i] = y; nt[(size_t)i * T + j] = y;
+                    acc += (double)y * (double)y;
+                }
+            trYTY = (double)(real)acc;
+            if (Yd_tn.upload(tn.data(), tn.size()) || Yd_nt.upload(nt.data(), nt.size())) return kFail;
+        }
         if (lag_set.upload(lags, nlag)) return kFail;
         if (upload_padded(W, (const real *)Wm->val, T)) return kFail;
         if (upload_padded(H, (const real *)Hm->val, n)) return kFail;
         if (theta.upload((const real *)LVm->val, (size_t)nlag * k)) return kFail;
 
         const size_t NV = (size_t)T * KP;
-        if (G.alloc((size_t)T * k * k) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
+        if (full) {
+            const size_t big = (size_t)std::max(T, n);
+            if (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k) ||
+                sgram_part.alloc((size_t)kSmallGramBlocks * k * k) ||
+                (dense && gemm_part.alloc((size_t)kGemmChunks * big * KP)))
+                return kFail;
+        }
+        if (G.alloc(full ? 1 : (size_t)T * k * k) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
             d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
             lossrow.alloc(T) || partials.alloc((size_t)P_NSLOTS * kMaxPartials) || xstate.alloc(1) ||
             log.alloc(kLogCap))
@@ -165,10 +203,18 @@ struct TrmfSessionImpl {
         }
         xp.T = T; xp.k = k; xp.KP = KP; xp.NT = NT; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
+        xp.full = full ? 1 : 0; xp.gstride = full ? 0 : (size_t)k * k; xp.trYTY = trYTY;
 
         fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1);
-        partition_by_nnz<size_t>((uint64_t)n, Y->col_ptr, comm->world, fbounds.data());
-        partition_by_nnz<size_t>((uint64_t)T, Y->row_ptr, comm->world, xbounds.data());
+        if (!dense) {
+            partition_by_nnz<size_t>((uint64_t)n, Y->col_ptr, comm->world, fbounds.data());
+            partition_by_nnz<size_t>((uint64_t)T, Y->row_ptr, comm->world, xbounds.data());
+        } else {
+            for (int r = 0; r <= comm->world; r++) {
+                fbounds[r] = (uint64_t)n * r / comm->world;
+                xbounds[r] = (uint64_t)T * r / comm->world;
+            }
+        }
 
         events.resize(kEventRing);
         for (auto &e : events) {
@@ -331,6 +377,72 @@ struct TrmfSessionImpl {
         return all_rows ? 0 : gather_rows(lossrow.p, xbounds, sizeof(double));
     }
 
+    // ---- full-observation path (missing == 0): trmf.cpp:299-351 and 155-215 -----------------------------
+    template <int NT_> void launch_spmm(const uint32_t *ptr, const uint32_t *idx, const real *val, const real *X,
+                                        real *out, uint32_t rb, uint32_t re, uint32_t zero_row) {
+        if (re > rb)
+            hipLaunchKernelGGL((spmm_rows_kernel<NT_>), dim3((re - rb + 3) / 4), dim3(256), 0, stream, ptr, idx, val, X,
+                               out, rb, re, zero_row);
+    }
+    template <int NT_> void launch_dense_tn(const real *A, int K, int M, const real *B, real *out) {
+        hipLaunchKernelGGL((dense_tn_kernel<NT_>), dim3((M + 255) / 256, kGemmChunks), dim3(256), 0, stream, A, K, M, B,
+                           gemm_part.p);
+        hipLaunchKernelGGL(dense_tn_reduce_kernel, dim3((unsigned)(((size_t)M * KP + 255) / 256)), dim3(256), 0, stream,
+                           gemm_part.p, kGemmChunks, M, KP, NT, k, out);
+    }
+    // out (rows x KP, logical columns) = op(Y) * X, rows [rb, re) (dense: all rows)
+    int y_times_factor(bool transposed, const real *X, real *out, uint32_t rb, uint32_t re) {
+        if (!dense) {
+            const uint32_t *ptr = transposed ? Yc_ptr.p : Yr_ptr.p, *idx = transposed ? Yc_idx.p : Yr_idx.p;
+            const real *val = transposed ? Yc_val.p : Yr_val.p;
+            const uint32_t zr = (uint32_t)(transposed ? T : n);
+            switch (NT) {
+                case 1: launch_spmm<1>(ptr, idx, val, X, out, rb, re, zr); break;
+                case 2: launch_spmm<2>(ptr, idx, val, X, out, rb, re, zr); break;
+                case 3: launch_spmm<3>(ptr, idx, val, X, out, rb, re, zr); break;
+                default: launch_spmm<4>(ptr, idx, val, X, out, rb, re, zr); break;
+            }
+        } else {
+            const real *A = transposed ? Yd_tn.p : Yd_nt.p;     // K x M row-major with K the contracted dim
+            const int K = transposed ? T : n, M = transposed ? n : T;
+            switch (NT) {
+                case 1: launch_dense_tn<1>(A, K, M, X, out); break;
+                case 2: launch_dense_tn<2>(A, K, M, X, out); break;
+                case 3: launch_dense_tn<3>(A, K, M, X, out); break;
+                default: launch_dense_tn<4>(A, K, M, X, out); break;
+            }
+        }
+        TRMF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    int small_gram(const real *A, int rows, real lambda, real *GS) {
+        const int nb = std::min(kSmallGramBlocks, std::max(1, rows));
+        hipLaunchKernelGGL(small_gram_kernel, dim3(nb), dim3(256), 0, stream, A, rows, KP, NT, k, sgram_part.p);
+        hipLaunchKernelGGL(small_gram_reduce_kernel, dim3(1), dim3(256), 0, stream, sgram_part.p, nb, k, lambda, GS);
+        return 0;
+    }
+    int fsolve_full(PhaseEvents &ev) {
+        const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
+        TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        if (y_times_factor(true, W.p, Bf.p, dense ? 0u : rb, dense ? (uint32_t)n : re)) return kFail;   // Y^T W
+        small_gram(W.p, T, (real)lambdaI, GSf.p);                                                       // W^T W + lambda I
+        if (re > rb) {
+            const size_t lds = ((size_t)k * k + 256 * (size_t)k) * sizeof(real);
+            hipLaunchKernelGGL(solve_shared_kernel, dim3((re - rb + 255) / 256), dim3(256), lds, stream, GSf.p,
+                               Bf.p + (size_t)rb * KP, H.p + (size_t)rb * KP, (int)(re - rb), k, KP, NT);
+        }
+        TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+        TRMF_HIP_CHECK(hipGetLastError());
+        return gather_rows(H.p, fbounds, (size_t)KP * sizeof(real));
+    }
+    int xprepare_full() {        // init() of arr_ls_fY_IX, trmf.cpp:183-187
+        const uint32_t rb = (uint32_t)xbounds[comm->rank], re = (uint32_t)xbounds[comm->rank + 1];
+        if (y_times_factor(false, H.p, Bv.p, dense ? 0u : rb, dense ? (uint32_t)T : re)) return kFail;  // Y H
+        if (!dense && gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
+        small_gram(H.p, n, real(0), GSx.p);                                                             // H^T H
+        return 0;
+    }
+
     // ---- X-solve (trmf.cpp:665-674 -> rf_tron.h:134-254) -----------------------------------------------
     // out = H*v (or the gradient when minus_b): fused LDS-tiled kernel when the AR halo fits, else the
     // ar_residual + apply pair.  `fuse`: v is the previous direction and the new one is formed on the fly.
@@ -342,10 +454,10 @@ struct TrmfSessionImpl {
             const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
             if (fuse)
                 hipLaunchKernelGGL((hv_tile_kernel<true>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, nbe,
-                                   v, rvec, dnew, lag_set.p, theta.p, G.p, Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
+                                   v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
             else
                 hipLaunchKernelGGL((hv_tile_kernel<false>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, nbe,
-                                   v, rvec, dnew, lag_set.p, theta.p, G.p, Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
+                                   v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
         } else {
             if (fuse)
                 hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
@@ -354,18 +466,23 @@ struct TrmfSessionImpl {
                 hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
                                    v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
             hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
-                               lag_set.p, theta.p, G.p, Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb);
+                               lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb);
         }
         return 0;
     }
+    const real *Gmat() const { return full ? GSx.p : G.p; }      // shared H^T H or the per-timestamp cache
     int np_base() const { return tile_TI > 0 ? nbt : nbe; }   // blocks that wrote P_AR / P_VV
     int np_dot() const { return tile_TI > 0 ? nbt : nba; }    // blocks that wrote P_DOT
 
     int xsolve() {
         XState *st = xstate.p;
         double *Pb = partials.p;
-        if (gram_x()) return kFail;                                            // G, b, loss(w)
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss0);
+        if (full) {
+            if (xprepare_full()) return kFail;                                 // b = Y H, shared Gram H^T H
+        } else {
+            if (gram_x()) return kFail;                                        // G, b, loss(w)
+            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss0);
+        }
         hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0);           // gradient, <g,g>, AR/ridge sums
         hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, np_base(), np_dot(), g.p,
                            s.p, r.p, d0.p);
@@ -434,7 +551,7 @@ struct TrmfSessionImpl {
             const bool doX = period_W > 0 && (iter1 % period_W) == 0;
             const bool doL = period_Lag > 0 && (iter1 % period_Lag) == 0;
             if (doF) {
-                if (fsolve(ev)) return kFail;
+                if (full ? fsolve_full(ev) : fsolve(ev)) return kFail;
                 log_norm(H.p, (size_t)n * KP, &L->normF);
                 if (verbose) fprintf(stderr, ">> iter %d F %g\n", iter1, host_double(&L->normF));
             } else {
@@ -511,6 +628,7 @@ struct TrmfSessionImpl {
 
     // J = 0.5*sum_Omega (Y - w.h)^2 + 0.5*lambdaI(|W|^2+|H|^2) + 0.5*lambdaAR*AR(W;Theta)  
     double objective() {
+        if (full) return NAN;       // defined for the observed-entries objective only
         XState *st = xstate.p;
         if (loss(W.p, true)) return NAN;
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss1);

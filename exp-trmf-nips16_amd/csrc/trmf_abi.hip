@@ -57,8 +57,9 @@ static bool check_dimension(const PyMatrix *Y, const PyMatrix *W, const PyMatrix
 // Limits of the device path (documented in DESIGN.md); violations are reported, never worked around.
 static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t lag_size, int missing) {
     bool pass = true;
-    if (!missing) { fprintf(stderr, "[ERR MSG]: missing=0 (full-observation path) is not implemented on the MI355X path yet\n"); pass = false; }
+    // the reference asserts (aborts) on a dense Y with missing != 0 (rf_matrix.h:180); here: diagnostic
     if (missing && Y->type != TRMF_SPARSE) { fprintf(stderr, "[ERR MSG]: missing!=0 requires a sparse Y\n"); pass = false; }
+    if (Y->type != TRMF_SPARSE && Y->type != TRMF_DENSE_ROWMAJOR && Y->type != TRMF_DENSE_COLMAJOR) { fprintf(stderr, "[ERR MSG]: unsupported Y matrix type %d\n", (int)Y->type); pass = false; }
     if (W->cols < 1 || W->cols > (uint64_t)kMaxRank) { fprintf(stderr, "[ERR MSG]: rank k=%ld outside the supported range 1..%d\n", (long)W->cols, kMaxRank); pass = false; }
     if (lag_size > (uint32_t)kMaxLags) { fprintf(stderr, "[ERR MSG]: |lag_set|=%u exceeds the supported %d\n", lag_size, kMaxLags); pass = false; }
     if (Y->nnz >= (1ull << 32) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
@@ -78,6 +79,7 @@ static TrmfSessionImpl *make_session(const PyMatrix *Y, const uint32_t *lag_set,
     std::unique_ptr<TrmfSessionImpl> s(new TrmfSessionImpl());
     s->lambdaI = lambdaI; s->lambdaAR = lambdaAR; s->lambdaLag = lambdaLag;
     s->period_W = period_W; s->period_H = period_H; s->period_Lag = period_Lag; s->verbose = verbose;
+    s->full = (missing == 0);
     if (s->create(Y, lag_set, lag_size, W, H, LV)) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
     return s.release();
 }

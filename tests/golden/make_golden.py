@@ -48,10 +48,10 @@ class capture_fds(object):
             os.close(fd)
 
 
-def run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
+def run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2), missing=True):
     W, H, Th = W0.copy(), H0.copy(), np.asfortranarray(Th0.copy())
     with capture_fds() as cap:
-        O.train_ref(Y, lag_set, W, H, Th, hyper, max_iter=max_iter, periods=periods, threads=4, missing=True, verbose=2)
+        O.train_ref(Y, lag_set, W, H, Th, hyper, max_iter=max_iter, periods=periods, threads=4, missing=missing, verbose=2)
     normF = np.full(max_iter, -1.0); normX = np.full(max_iter, -1.0); normLV = np.full(max_iter, -1.0)
     for line in cap.err:
         m = re.match(r'>> iter (\d+) (F|X|LV) (\S+)$', line.strip())
@@ -63,6 +63,34 @@ def run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
         if m:
             fx.append(float(m.group(1))); cg.append(int(m.group(2)))
     return W, H, Th, normF, normX, normLV, np.array(cg, dtype=np.int32), np.array(fx)
+
+
+def make_full_case(name, n, T, k, lag_set, dtype, max_iter, seed=0, hyper=None, sparse_density=None, order='C'):
+    """missing=0 (full-observation path, trmf.cpp:155-215,299-351): dense Y, or sparse Y whose zeros count."""
+    hyper = dict(hyper or synth.HYPER)
+    from trmf import Model
+    lag_set = np.array(sorted(lag_set), dtype=np.uint32)
+    d = Model.syn_gen(T, n, k, lag_set, seed=seed, dtype=dtype)
+    Yd = d['Y'] + np.asarray(0.05 * np.random.RandomState(seed).randn(T, n), dtype=dtype)
+    if sparse_density is not None:
+        mask = np.random.RandomState(seed + 1).rand(T, n) < sparse_density
+        Y = smat.csr_matrix(np.where(mask, Yd, 0).astype(dtype)); Y.sort_indices()
+    else:
+        Y = np.asarray(Yd, dtype=dtype, order=order)
+    model = synth.initial_model(Y, lag_set, k, seed=seed, dtype=dtype)
+    W0, H0, Th0 = model.W.copy(), model.H.copy(), np.asfortranarray(model.lag_val.copy())
+    W, H, Th, nF, nX, nLV, cg, fx = run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, missing=False)
+    path = os.path.join(OUT, name + '.npz')
+    common = dict(shape=np.array([T, n]), lag_set=lag_set, W0=W0, H0=H0, Th0=Th0, W=W, H=H, Th=Th,
+                  normF=nF, normX=nX, normLV=nLV, cg_iter=cg, f_x=fx, objective=np.array(np.nan), missing=np.array(0),
+                  lambdaI=hyper['lambdaI'], lambdaAR=hyper['lambdaAR'], lambdaLag=hyper['lambdaLag'], max_iter=np.array(max_iter))
+    if sparse_density is not None:
+        np.savez_compressed(path, Y_indptr=Y.indptr.astype(np.int64), Y_indices=Y.indices.astype(np.int32), Y_data=Y.data, **common)
+    else:
+        np.savez_compressed(path, Y_dense=Y, Y_order=np.array(order), **common)
+    print('{:>14s}: T={} n={} k={} full {} {} iters={} cg={} ({} KB)'.format(
+        name, T, n, k, 'sparse' if sparse_density is not None else 'dense-' + order, np.dtype(dtype).name, max_iter,
+        cg.tolist(), os.path.getsize(path) // 1024))
 
 
 def make_case(name, n, T, k, lag_set, density, dtype, max_iter, seed=0, hyper=None, drop_rows=(), drop_cols=()):
@@ -102,6 +130,10 @@ def main():
     make_case('k40_f32', n=500, T=300, k=40, lag_set=list(range(1, 17)), density=0.2, dtype=np.float32, max_iter=4, seed=2)
     make_case('k64_f64', n=260, T=220, k=64, lag_set=[1, 2, 4, 8, 16, 32], density=0.45, dtype=np.float64, max_iter=3, seed=4)
     make_case('one_iter_f64', n=300, T=200, k=24, lag_set=[1, 2, 24], density=0.15, dtype=np.float64, max_iter=1, seed=5)
+    # full-observation path (missing=0): electricity-like tall dense matrix (BASELINE config 1 shape class), F order, sparse
+    make_full_case('full_dense_f64', n=37, T=520, k=4, lag_set=[1, 2, 3], dtype=np.float64, max_iter=5, seed=6)
+    make_full_case('full_dense_f32', n=60, T=300, k=20, lag_set=[1, 2, 24], dtype=np.float32, max_iter=4, seed=7, order='F')
+    make_full_case('full_sparse_f64', n=150, T=200, k=9, lag_set=[0, 1, 5], dtype=np.float64, max_iter=4, seed=8, sparse_density=0.2)
 
 
 if __name__ == '__main__':

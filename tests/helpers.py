@@ -15,8 +15,12 @@ def golden_names():
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
     T, n = [int(v) for v in z['shape']]
-    Y = smat.csr_matrix((z['Y_data'], z['Y_indices'], z['Y_indptr']), shape=(T, n))
+    if 'Y_dense' in z.files:
+        Y = np.asarray(z['Y_dense'], order=str(z['Y_order']))
+    else:
+        Y = smat.csr_matrix((z['Y_data'], z['Y_indices'], z['Y_indptr']), shape=(T, n))
     g = {k: z[k] for k in z.files}
+    g['missing'] = bool(int(z['missing'])) if 'missing' in z.files else True
     g['Y'] = Y
     g['hyper'] = dict(lambdaI=float(z['lambdaI']), lambdaAR=float(z['lambdaAR']), lambdaLag=float(z['lambdaLag']))
     g['max_iter'] = int(z['max_iter'])

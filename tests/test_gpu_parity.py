@@ -13,10 +13,10 @@ from trmf import session, synth
 pytestmark = pytest.mark.gpu
 
 
-def run_product(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
+def run_product(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2), missing=True):
     model = make_model(W0, H0, Th0, lag_set)
     trmf.train(Y, model, max_iter=max_iter, period_W=periods[0], period_H=periods[1], period_Lag=periods[2],
-               missing=True, **hyper)
+               missing=missing, **hyper)
     return model
 
 
@@ -30,9 +30,9 @@ def test_one_fsolve_matches_golden_inputs(name):
     """One F-solve only (period_W, period_Lag > max_iter) vs the restatement: direct solve, tight gate."""
     g = load_golden(name)
     big = 10 ** 6
-    m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], 1, periods=(big, 1, big))
+    m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], 1, periods=(big, 1, big), missing=g['missing'])
     W, H, Th = g['W0'].copy(), g['H0'].copy(), np.asfortranarray(g['Th0'].copy())
-    O.train_port(g['Y'], g['lag_set'], W, H, Th, g['hyper'], max_iter=1, periods=(big, 1, big))
+    O.train_port(g['Y'], g['lag_set'], W, H, Th, g['hyper'], max_iter=1, periods=(big, 1, big), missing=g['missing'])
     tol = 1e-6 if g['dtype'] == np.float64 else 2e-4          # fp64 gate: max|d|/max|ref| <= 1e-6
     assert relmax(m.H, H) < tol
     assert np.array_equal(m.W, g['W0']) and np.array_equal(m.lag_val, g['Th0'])     # untouched phases
@@ -41,13 +41,19 @@ def test_one_fsolve_matches_golden_inputs(name):
 @pytest.mark.parametrize('name', golden_names())
 def test_full_run_matches_golden(name):
     g = load_golden(name)
-    m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], g['max_iter'])
+    m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], g['max_iter'], missing=g['missing'])
     tol = TOL[np.dtype(g['dtype']).name]
     assert relfro(m.W, g['W']) < tol['factor']
     assert relfro(m.H, g['H']) < tol['factor']
     assert relfro(m.lag_val, g['Th']) < tol['factor'] * 10
-    J = O.objective(g['Y'], g['lag_set'], m.W, m.H, m.lag_val, g['hyper'])
-    assert abs(J - float(g['objective'])) / float(g['objective']) < tol['objective']
+    if g['missing']:
+        J = O.objective(g['Y'], g['lag_set'], m.W, m.H, m.lag_val, g['hyper'])
+        assert abs(J - float(g['objective'])) / float(g['objective']) < tol['objective']
+    else:       # full-observation objective, evaluated densely in fp64 on both outputs
+        Yd = g['Y'].toarray() if smat.issparse(g['Y']) else np.asarray(g['Y'])
+        def J_full(W, H):
+            return 0.5 * np.sum((Yd.astype(np.float64) - W.astype(np.float64) @ H.astype(np.float64).T) ** 2)
+        assert abs(J_full(m.W, m.H) - J_full(g['W'], g['H'])) / J_full(g['W'], g['H']) < max(tol['objective'], 1e-7)
 
 
 @pytest.mark.parametrize('name', golden_names())
@@ -55,10 +61,10 @@ def test_session_log_matches_reference_observables(name):
     """Norms the reference prints (trmf.cpp:661,672,687) and its CG step counts (rf_tron.h:219)."""
     g = load_golden(name)
     model = make_model(g['W0'], g['H0'], g['Th0'], g['lag_set'])
-    with session.Session(g['Y'], model, missing=True, **g['hyper']) as s:
+    with session.Session(g['Y'], model, missing=g['missing'], **g['hyper']) as s:
         s.run(g['max_iter'])
         st = s.stats(g['max_iter'])
-        Jdev = s.objective()
+        Jdev = s.objective() if g['missing'] else None
         s.download()
     assert len(st) == g['max_iter']
     rtol = 2e-5 if g['dtype'] == np.float64 else 2e-4
@@ -72,8 +78,9 @@ def test_session_log_matches_reference_observables(name):
         assert cg.tolist() == g['cg_iter'].tolist()
     assert all(x['accepted'] == 1 for x in st)
     assert np.allclose([x['f'] for x in st], g['f_x'], rtol=2e-3)   # %5.3e in the TRON line
-    J = O.objective(g['Y'], g['lag_set'], model.W, model.H, model.lag_val, g['hyper'])
-    assert abs(Jdev - J) / J < 1e-5
+    if g['missing']:
+        J = O.objective(g['Y'], g['lag_set'], model.W, model.H, model.lag_val, g['hyper'])
+        assert abs(Jdev - J) / J < 1e-5
 
 
 @pytest.mark.parametrize('dtype,k,nlag', [(np.float32, 16, 8), (np.float32, 40, 16), (np.float64, 24, 4),
@@ -144,8 +151,11 @@ def test_unsupported_inputs_fail_loudly(capfd):
     m0 = synth.initial_model(smat.csr_matrix(Yd), [1, 2], 4, seed=0)
     W0 = m0.W.copy()
     model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
-    trmf.train(Yd, model, missing=False, max_iter=1)
-    assert 'missing=0' in capfd.readouterr().err and np.array_equal(model.W, W0)
+    trmf.train(Yd, model, missing=True, max_iter=1)                 # dense Y needs missing=False
+    assert 'requires a sparse Y' in capfd.readouterr().err and np.array_equal(model.W, W0)
+    big = make_model(np.zeros((30, 65), np.float32), np.zeros((20, 65), np.float32), np.zeros((2, 65), np.float32, order='F'), [1, 2])
+    trmf.train(smat.csr_matrix(Yd), big, missing=True, max_iter=1)
+    assert 'outside the supported range' in capfd.readouterr().err
 
 
 def test_full_size_headline_properties():
