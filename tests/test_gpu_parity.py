@@ -188,3 +188,42 @@ def test_full_size_headline_properties():
             assert st['accepted'] == 1 and 1 <= st['cg_iter'] <= 20
             assert abs(st['actred'] - st['prered']) <= 2e-3 * abs(st['prered']) + 1e-3 * abs(st['f'])   # quadratic model
     assert all(J[i + 1] < J[i] for i in range(len(J) - 1)), J
+
+
+def test_config1_electricity_shape_full_observation():
+    """BASELINE config 1: dense 26 304 x 370 (electricity shape; data unavailable offline -> syn_gen-style
+    low-rank + AR), k=4, L={1,2,3}, fp64, missing=0, vs the restatement (fp64 gates)."""
+    T, n, k, lags = 26304, 370, 4, [1, 2, 3]
+    d = trmf.Model.syn_gen(T, n, k, lags, seed=0, dtype=np.float64)
+    Y = d['Y'] + 0.05 * np.random.RandomState(0).randn(T, n)
+    m0 = trmf.Model.initialize(Y, lags, k, seed=0)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    hyper = dict(lambdaI=0.5, lambdaAR=125.0, lambdaLag=2.0)          # run_electricity.py:9-25
+    O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=3, missing=False, threads=8)
+    m = run_product(Y, m0.lag_set, m0.W, m0.H, m0.lag_val, hyper, 3, missing=False)
+    assert relmax(m.W, W) < 1e-6 and relmax(m.H, H) < 1e-6 and relmax(m.lag_val, Th) < 1e-5
+    J = lambda A, B: 0.5 * np.sum((Y - A @ B.T) ** 2)
+    assert abs(J(m.W, m.H) - J(W, H)) / J(W, H) < 1e-8
+
+
+def test_rolling_validate_harness_on_gpu_matches_oracle_harness():
+    """the Python harness (initialize -> train -> forecast -> warm start) run through
+    the GPU path gives the same forecasts/metrics as the same harness with the restatement as trainer."""
+    T, n, k, lags = 400, 60, 6, [1, 2, 7]
+    d = trmf.Model.syn_gen(T, n, k, lags, seed=3, dtype=np.float64)
+    Y = np.abs(d['Y']) + 0.1
+    kw = dict(k=k, window_size=12, nr_windows=3, lambdaI=0.5, lambdaAR=50, lambdaLag=0.5, max_iter=5, seed=0)
+    got = trmf.rolling_validate(Y, lags, missing=True, threshold=0, **kw)
+
+    # the same loop (trmf/validate.py == reference trmf.py:303-329) with the oracle as the trainer
+    trueY = Y[-36:, :]; forecastY = np.zeros_like(trueY); prev = None
+    for i in range(3):
+        trn_end = T - (3 - i) * 12
+        Ytrn = smat.csr_matrix(Y[:trn_end])
+        cur = trmf.Model.initialize(Ytrn, lags, k, seed=0, warm_start_model=prev)
+        O.train_port(Ytrn, cur.lag_set, cur.W, cur.H, cur.lag_val, dict(lambdaI=0.5, lambdaAR=50, lambdaLag=0.5), max_iter=5)
+        cur.forecast(12, Ynew=forecastY[i * 12:(i + 1) * 12, :], threshold=0)
+        prev = cur
+    want = trmf.Metrics.generate(trueY, forecastY)
+    for field in want._fields:
+        assert abs(getattr(got, field) - getattr(want, field)) <= 1e-6 * abs(getattr(want, field)) + 1e-9, field
