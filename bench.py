@@ -112,7 +112,8 @@ def main():
         raise SystemExit('WORLD_SIZE={} but --gpus {}'.format(world, args.gpus))
 
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get('TRMF_BENCH_FORCE_DIST'))   # override: exercise this branch with 1 rank
+    if use_dist:
         # torch first: its bundled HIP/RCCL runtimes must be the ones this process binds to
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -132,7 +133,7 @@ def main():
     if lib.trmf_set_device(local_rank) != 0:
         raise SystemExit(lib.trmf_last_error().decode())
 
-    if world > 1:
+    if use_dist:
         import ctypes
         ident = [None]
         if rank == 0:
