@@ -47,6 +47,17 @@ def physical_cores():
         return os.cpu_count() or 1
 
 
+def make_problem(cfg):
+    """(problem dict, hyper-parameters, missing flag) of a synth.CONFIGS entry."""
+    import numpy as np
+    from trmf import synth
+    dtype = np.dtype(cfg['dtype'])
+    if cfg.get('dense'):
+        return synth.dense_problem(cfg['n'], cfg['T'], cfg['k'], cfg['lags'], dtype=dtype, seed=0), dict(cfg['hyper']), False
+    return (synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=dtype, seed=0),
+            dict(synth.HYPER), True)
+
+
 def cpu_baseline_worker(config, iters, kind, threads):
     """Child process: time `iters` ALS iterations of the CPU path; prints one JSON line."""
     os.environ['OPENBLAS_NUM_THREADS'] = '1'   # before NumPy loads OpenBLAS: its pool fights OpenMP
@@ -55,12 +66,12 @@ def cpu_baseline_worker(config, iters, kind, threads):
     import oracle_py as O                      # test infrastructure: the checker / CPU baseline only
     from trmf import synth
     cfg = synth.CONFIGS[config]
-    prob = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.dtype(cfg['dtype']), seed=0)
+    prob, hyper, missing = make_problem(cfg)
     m0 = synth.initial_model(prob['Y'], prob['lag_set'], cfg['k'], seed=0)
     W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
     run = O.train_ref if kind == 'reference' else O.train_port
     t0 = time.perf_counter()
-    run(prob['Y'], prob['lag_set'], W, H, Th, synth.HYPER, max_iter=iters, threads=threads)
+    run(prob['Y'], prob['lag_set'], W, H, Th, hyper, max_iter=iters, threads=threads, missing=missing)
     print(json.dumps({'seconds': time.perf_counter() - t0}))
 
 
@@ -145,9 +156,8 @@ def main():
         if lib.trmf_dist_init(rank, world, ident[0]) != 0:
             raise SystemExit(lib.trmf_last_error().decode())
 
-    hyper = dict(synth.HYPER)
     t_gen = time.perf_counter()
-    prob = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=dtype, seed=0)
+    prob, hyper, missing = make_problem(cfg)
     model = synth.initial_model(prob['Y'], prob['lag_set'], cfg['k'], seed=0)
     t_gen = time.perf_counter() - t_gen
 
@@ -162,7 +172,7 @@ def main():
             torch.cuda.synchronize()
 
     t_up = time.perf_counter()
-    s = session.Session(prob['Y'], model, missing=True, **hyper)
+    s = session.Session(prob['Y'], model, missing=missing, **hyper)
     t_up = time.perf_counter() - t_up
     s.run(args.warmup)
     device_sync(s); barrier()
@@ -183,7 +193,7 @@ def main():
     s.close()
 
     if rank == 0:
-        nnz = int(prob['Y'].nnz)
+        nnz = int(prob['Y'].nnz) if hasattr(prob['Y'], 'nnz') else int(prob['Y'].size)
         achieved = bytes_f / (ms_fk * 1e-3) / 1e9 if ms_fk > 0 else 0.0
         traffic = None      # HBM bytes per launch from the committed PMC profile of this config (1 GPU only)
         try:
@@ -198,9 +208,9 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if dtype == np.float32 else 'f64',
             'data': 'synthetic',
-            'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing=1 lambdaI={} lambdaAR={} lambdaLag={}'.format(
-                args.config, cfg['n'], cfg['T'], cfg['density'], nnz, cfg['k'], cfg['nlag'], dtype.name,
-                hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
+            'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
+                args.config, cfg['n'], cfg['T'], cfg.get('density', 1.0), nnz, cfg['k'], len(prob['lag_set']), dtype.name,
+                int(missing), hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
                 'parallelism': 'F rows / X-Gram rows sharded x{}, CG replicated'.format(world)},
             'roofline': {'kernel': 'fsolve_quad_kernel<3,40>' if dtype == np.float32 else 'fsolve_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,

@@ -452,12 +452,13 @@ struct TrmfSessionImpl {
         double *Pb = partials.p;
         if (tile_TI > 0) {
             const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
-            if (fuse)
-                hipLaunchKernelGGL((hv_tile_kernel<true>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, nbe,
-                                   v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
-            else
-                hipLaunchKernelGGL((hv_tile_kernel<false>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, nbe,
-                                   v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, Pb, tile_TI, rpb);
+#define TRMF_LAUNCH_HV(FUSE, GRAD)                                                                      \
+            hipLaunchKernelGGL((hv_tile_kernel<FUSE, GRAD>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, \
+                               nbe, v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, out, dot_mode, Pb, tile_TI, rpb)
+            if (fuse) TRMF_LAUNCH_HV(true, false);
+            else if (minus_b) TRMF_LAUNCH_HV(false, true);
+            else TRMF_LAUNCH_HV(false, false);
+#undef TRMF_LAUNCH_HV
         } else {
             if (fuse)
                 hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,

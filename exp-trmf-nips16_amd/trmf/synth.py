@@ -41,8 +41,21 @@ def initial_model(Y, lag_set, k, seed=0, dtype=None):
     return Model.initialize(Y, lag_set, k, seed=seed, dtype=dtype)
 
 
+def dense_problem(n, T, k, lag_set, dtype=np.float64, seed=0, noise=0.05):
+    """Dense low-rank + AR matrix (Model.syn_gen + observation noise): stand-in for the electricity /
+    traffic matrices, which are not available offline."""
+    from .model import Model
+    d = Model.syn_gen(T, n, k, lag_set, seed=seed, dtype=np.float64)
+    Y = d['Y'] + noise * np.random.RandomState(seed).randn(T, n)
+    return {'Y': np.ascontiguousarray(Y, dtype=dtype), 'lag_set': d['lag_set']}
+
+
 # BASELINE.json configs (index = position in BASELINE.json:configs)
 CONFIGS = {
+    # config 1: electricity shape, dense, full-observation path (missing=0), hyper-parameters of
+    # python/exp-scripts/run_electricity.py:9-25 (k and lags as BASELINE.json states them)
+    'c1': dict(n=370, T=26304, k=4, lags=[1, 2, 3], dense=True, dtype='float64',
+               hyper=dict(lambdaI=0.5, lambdaAR=125.0, lambdaLag=2.0)),
     'c2': dict(n=10000, T=5000, k=16, nlag=8, density=0.01, dtype='float32'),
     'c3': dict(n=100000, T=10000, k=40, nlag=16, density=0.01, dtype='float32'),
     'c5': dict(n=1000000, T=50000, k=64, nlag=32, density=0.001, dtype='float64'),
