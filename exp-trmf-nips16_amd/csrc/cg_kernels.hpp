@@ -251,7 +251,7 @@ __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, in
 
 // GRAD: gradient call (subtracts b, emits the quadratic-loss partial of the full path); compile-time so that
 // the 20 Hessian-vector calls per solve carry none of it (measured: +0.3 ms per solve as a runtime flag)
-template <bool FUSE_DIR, bool GRAD>
+template <bool FUSE_DIR, bool GRAD, int NT_T>
 __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *__restrict__ st,
                                                       const double *__restrict__ Prr_cur,
                                                       const double *__restrict__ Prr_prev, int np,
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
                                                       const real *__restrict__ theta,
                                                       const real *__restrict__ G,
                                                       const real *__restrict__ Bv,
-                                                      real *__restrict__ out, int dot_mode,
+                                                      real *__restrict__ out,
                                                       double *__restrict__ Pbase, int TI, int rpb) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
             if (cg_stopped(rho, st->cgtol)) return;
         }
     }
-    const int k = p.k, KP = p.KP, T = p.T, Hh = p.midx, nlag = p.nlag;
+    const int k = p.k, T = p.T, Hh = p.midx, nlag = p.nlag;
+    constexpr int KP = kTile * NT_T;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
         // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139)
         for (int e = threadIdx.x; e < rowsR * KP; e += 256) {
             const int rr = e / KP, tp = e - rr * KP, i = i0 + rr;         // tp: position, t: logical column
-            const int t = collog(tp, p.NT);
+            const int t = collog(tp, NT_T);
             double res = 0;
             if (ar_on && t < k && i >= Hh && i < T) {
                 res = (double)vs[(rr + Hh) * KP + tp];
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
         // (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b), `rpb` rows per pass.  The cached Gram is the
         //     only HBM-sized stream of the CG: kGChunk loads are kept in flight per thread.
         const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;   // t: logical column
-        const int tp = colpos(t, p.NT);
+        const int tp = colpos(t, NT_T);
         for (int r0 = 0; r0 < TI; r0 += rpb) {
             const int rr = r0 + lr, i = i0 + rr;
             if (lr < rpb && rr < TI && i < T) {
@@ -337,12 +338,12 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
                 const real *vi = vs + (rr + Hh) * KP;
                 double acc = 0;
 // logical column s2 = 16q + c sits at position NT*c + q: two constant-stride loops
-                for (int q = 0; q < p.NT; q++) {
+                for (int q = 0; q < NT_T; q++) {
                     const int cn = min(kTile, k - kTile * q);
                     const real *Gq = Gi + (size_t)(kTile * q) * k;
                     const real *vq = vi + q;
 #pragma unroll 8
-                    for (int c2 = 0; c2 < cn; c2++) acc += (double)Gq[(size_t)c2 * k] * (double)vq[c2 * p.NT];
+                    for (int c2 = 0; c2 < cn; c2++) acc += (double)Gq[(size_t)c2 * k] * (double)vq[c2 * NT_T];
                 }
                 real o;
                 if (p.lambdaI == 0) o = 0;
@@ -363,7 +364,7 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
                 }
                 o = (real)((double)o + acc);
                 out[(size_t)i * KP + tp] = o;
-                dot += (double)(dot_mode ? x : o) * (double)o;
+                dot += (double)(GRAD ? o : x) * (double)o;     // <g,g> for the gradient, <v,Hv> otherwise
             }
         }
     }

@@ -452,12 +452,20 @@ struct TrmfSessionImpl {
         double *Pb = partials.p;
         if (tile_TI > 0) {
             const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
+#define TRMF_LAUNCH_HV_NT(FUSE, GRAD, NTT)                                                              \
+            hipLaunchKernelGGL((hv_tile_kernel<FUSE, GRAD, NTT>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur,  \
+                               Pprev, nbe, v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, out, Pb, tile_TI, rpb)
 #define TRMF_LAUNCH_HV(FUSE, GRAD)                                                                      \
-            hipLaunchKernelGGL((hv_tile_kernel<FUSE, GRAD>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur, Pprev, \
-                               nbe, v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, out, dot_mode, Pb, tile_TI, rpb)
-            if (fuse) TRMF_LAUNCH_HV(true, false);
-            else if (minus_b) TRMF_LAUNCH_HV(false, true);
-            else TRMF_LAUNCH_HV(false, false);
+            switch (NT) {                                                                               \
+                case 1: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 1); break;                                         \
+                case 2: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 2); break;                                         \
+                case 3: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 3); break;                                         \
+                default: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 4); break;                                        \
+            }
+            if (fuse) { TRMF_LAUNCH_HV(true, false); }
+            else if (minus_b) { TRMF_LAUNCH_HV(false, true); }
+            else { TRMF_LAUNCH_HV(false, false); }
+#undef TRMF_LAUNCH_HV_NT
 #undef TRMF_LAUNCH_HV
         } else {
             if (fuse)
