@@ -33,6 +33,7 @@ struct XParams {
     // full-observation path (missing == 0, trmf.cpp:155-215): one shared Gram H^T H for every
     // timestamp (gstride == 0) and fun = base + 0.5*(tr Y^T Y + sum_i w_i^T G w_i - 2 b_i.w_i)
     int full;
+    int pstride;                       // entries between the partial-sum arrays (>= kMaxPartials, >= tile count)
     size_t gstride;                    // elements between consecutive per-timestamp Grams (k*k or 0)
     double trYTY;
 };
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XStat
     ar2 = block_allsum(ar2, smem);
     vv = block_allsum(vv, smem);
     if (threadIdx.x == 0) {
-        Pbase[P_AR * kMaxPartials + blockIdx.x] = ar2;
-        Pbase[P_VV * kMaxPartials + blockIdx.x] = vv;
+        Pbase[P_AR * (size_t)p.pstride + blockIdx.x] = ar2;
+        Pbase[P_VV * (size_t)p.pstride + blockIdx.x] = vv;
     }
 }
 
@@ -233,39 +234,105 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     }
     dot = block_allsum(dot, smem);
     lq = block_allsum(lq, smem);
-    if (threadIdx.x == 0) { Pdot[blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * kMaxPartials + blockIdx.x] = lq; }
+    if (threadIdx.x == 0) { Pdot[blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + blockIdx.x] = lq; }
 }
 
 // ---- fused Hessian-vector / gradient kernel, tiled over time in LDS --------------------------------
 // One launch = [direction update (FUSE_DIR)] + AR residual + AR adjoint + cached-Gram product
 // (ar_residual_kernel + apply_kernel above, same arithmetic and rounding sequence).  A workgroup owns
 // TI consecutive timestamps: it stages the operand rows [i0-midx, i0+TI+midx) in LDS, forms the AR
-// residuals of rows [i0, i0+TI+midx) there (the halo is recomputed, not exchanged), and then streams
-// its TI cached Grams once.  Used when the halo fits LDS (hv_tile_lds_bytes); otherwise the two-kernel
-// path runs.  dynamic LDS = hv_tile_lds_bytes(TI, midx, KP)
+// residuals of rows [i0, i0+TI+midx) there (the halo is recomputed, not exchanged), and multiplies its
+// TI cached Grams.  Used when the halo fits LDS (hv_tile_lds_bytes); otherwise the two-kernel path runs.
+//
+// The kernel is LATENCY-bound, not bandwidth-bound: the launch is a single wave of workgroups, each a
+// serial chain  partial sums -> operand -> residual -> Gram product.  So every global load of the chain
+// is issued at the very top, in the order it will be consumed (vmcnt retires in order): CG partials,
+// Theta/lag set, operand rows, and finally the thread's whole slice of the cached Gram (KQ 16-byte
+// loads, one timestamp row x 16/sizeof(real) columns per thread).  The Gram -- the only HBM-sized
+// stream of the CG, T*k*k values -- is then in flight for the entire launch while the chain runs on
+// registers and LDS underneath it.  Barriers wait on lgkmcnt only, so the loads stay outstanding.
+// dynamic LDS = hv_tile_lds_bytes(TI, midx, KP, nlag, k)
 __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, int nlag = 0, int k = 0) {
     const size_t a = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;
     const size_t b = ((size_t)(TI + midx) * KP * sizeof(double) + 15) / 16 * 16;
     return a + b + (size_t)nlag * k * sizeof(real) + (size_t)nlag * sizeof(int);   // + Theta, lag_set
 }
+constexpr int kHvThetaRegs = 3;                  // Theta elements per thread loaded ahead of the scalar prologue
+constexpr int kHvOperandRegs = 12;               // operand elements per thread requested ahead of the Gram
+constexpr int kHvGramPad = 4;                    // elements allocated past the Gram cache (vector tail reads)
+// Gram columns per thread: one 16-byte load per Gram row up to rank 40, 8-byte loads above (the thread's
+// slice, KQ loads, has to stay within ~160 of the 256 registers)
+__host__ __device__ constexpr int hv_vec(int KQ) { return (KQ <= 40 ? 16 : 8) / (int)sizeof(real); }
+__host__ __device__ constexpr int hv_kq(int k) { return (k + 7) / 8 * 8; }
+__host__ __device__ inline int hv_tile_rows(int k) { const int vec = hv_vec(hv_kq(k)); return 256 / ((k + vec - 1) / vec); }
+
+// VEC consecutive Gram entries through a raw buffer load: address = wave-uniform descriptor base (the
+// tile's first Gram) + scalar offset (Gram row j) + one 32-bit lane offset -- no per-load vector address.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_rsrc(const void *base, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)(bytes < 0x7fffffffu ? bytes : 0x7fffffffu),
+                                             0x00020000);
+}
+// element access at a BYTE offset; a byte offset at or past the descriptor's size reads 0 / drops the store
+template <typename R = real>
+__device__ __forceinline__ R buffer_load_real(__amdgpu_buffer_rsrc_t rsrc, int byte_off) {
+    if constexpr (sizeof(R) == 4) return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0));
+    else return __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0));
+}
+template <typename R = real>
+__device__ __forceinline__ void buffer_store_real(__amdgpu_buffer_rsrc_t rsrc, int byte_off, R x) {
+    if constexpr (sizeof(R) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, x), rsrc, byte_off, 0, 0);
+    else {
+        typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, x), rsrc, byte_off, 0, 0);
+    }
+}
+template <int VEC> struct GramVec { real c[VEC]; };
+template <int VEC>
+__device__ __forceinline__ GramVec<VEC> gram_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    if constexpr (VEC * sizeof(real) == 16)
+        return __builtin_bit_cast(GramVec<VEC>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+    else
+        return __builtin_bit_cast(GramVec<VEC>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+}
 
 // GRAD: gradient call (subtracts b, emits the quadratic-loss partial of the full path); compile-time so that
-// the 20 Hessian-vector calls per solve carry none of it (measured: +0.3 ms per solve as a runtime flag)
-template <bool FUSE_DIR, bool GRAD, int NT_T>
-__global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *__restrict__ st,
-                                                      const double *__restrict__ Prr_cur,
-                                                      const double *__restrict__ Prr_prev, int np,
-                                                      const real *__restrict__ v,
-                                                      const real *__restrict__ rvec,
-                                                      real *__restrict__ dnew,
-                                                      const uint32_t *__restrict__ lag_set,
-                                                      const real *__restrict__ theta,
-                                                      const real *__restrict__ G,
-                                                      const real *__restrict__ Bv,
-                                                      real *__restrict__ out,
-                                                      double *__restrict__ Pbase, int TI, int rpb) {
+// the 20 Hessian-vector calls per solve carry none of it (measured: +0.3 ms per solve as a runtime flag).
+// KQ = rank rounded up to 8 (Gram rows requested per thread).
+template <bool FUSE_DIR, bool GRAD, int KQ>
+__global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState *__restrict__ st,
+                                                         const double *__restrict__ Prr_cur,
+                                                         const double *__restrict__ Prr_prev, int np,
+                                                         const real *__restrict__ v,
+                                                         const real *__restrict__ rvec,
+                                                         real *__restrict__ dnew,
+                                                         const uint32_t *__restrict__ lag_set,
+                                                         const real *__restrict__ theta,
+                                                         const real *__restrict__ G,
+                                                         const real *__restrict__ Bv,
+                                                         real *__restrict__ out,
+                                                         double *__restrict__ Pbase, int TI) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
+    constexpr int VEC = hv_vec(KQ);
+    constexpr int NT_T = (KQ + kTile - 1) / kTile;
+    constexpr int KP = kTile * NT_T;
+    const int tid = threadIdx.x;
+    const int k = p.k, T = p.T, Hh = p.midx, nlag = p.nlag;
+    const int rowsV = TI + 2 * Hh, rowsR = TI + Hh, nV = rowsV * KP, nTh = nlag * k;
+    const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T);   // one tile per workgroup
+    real *vs = reinterpret_cast<real *>(hv_smem);
+    double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
+    real *ths = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
+    int *lags = reinterpret_cast<int *>(ths + (size_t)nlag * k);
+
+    // ---- scalar prologue: rho, stop test, beta; Theta / lag set to LDS (their loads fly with the partials) ----
+    real thr[kHvThetaRegs];
+    int lagr = 0;
+    if (nlag > 0) {
+#pragma unroll
+        for (int m = 0; m < kHvThetaRegs; m++) thr[m] = theta[min(tid + 256 * m, nTh - 1)];
+        lagr = (int)lag_set[min(tid, nlag - 1)];
+    }
     real tmp = 0;
     if (Prr_cur != nullptr) {
         if (FUSE_DIR) {
@@ -280,103 +347,188 @@ __global__ __launch_bounds__(256) void hv_tile_kernel(XParams p, const XState *_
             if (cg_stopped(rho, st->cgtol)) return;
         }
     }
-    const int k = p.k, T = p.T, Hh = p.midx, nlag = p.nlag;
-    constexpr int KP = kTile * NT_T;
-    const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
-    real *vs = reinterpret_cast<real *>(hv_smem);
-    double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
-    real *ths = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
-    int *lags = reinterpret_cast<int *>(ths + (size_t)nlag * k);
-    for (int e = threadIdx.x; e < nlag * k; e += 256) ths[e] = theta[e];     // Theta(l,t) at ths[t*nlag+l]
-    for (int e = threadIdx.x; e < nlag; e += 256) lags[e] = (int)lag_set[e];
-    const bool ar_on = nlag > 0 && p.lambdaAR > 0;
+    if (nlag > 0) {                                         // Theta(l,t) at ths[l*k+t]: lanes over t, distinct banks
+#pragma unroll
+        for (int m = 0; m < kHvThetaRegs; m++) {
+            const int e = tid + 256 * m, tt = e / nlag, l = e - tt * nlag;
+            if (e < nTh) ths[l * k + tt] = thr[m];
+        }
+#pragma nounroll
+        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) {
+            const int tt = e / nlag, l = e - tt * nlag;
+            ths[l * k + tt] = theta[e];
+        }
+        if (tid < nlag) lags[tid] = lagr;
+#pragma nounroll
+        for (int e = tid + 256; e < nlag; e += 256) lags[e] = (int)lag_set[e];
+    }
+    // ---- requests, in consumption order (vmcnt retires in order) ----
+    // (a) operand rows: the staged rows [i0-midx, i0+TI+midx) are one contiguous range of the vector,
+    //     stage element e = vector element (i0-midx)*KP + e.  Buffer descriptors do the clipping: an
+    //     offset outside the vector reads 0 (its negative wraps to a huge unsigned), and the direction
+    //     store goes through a descriptor that spans only the tile's own rows.
+    const int sz = (int)sizeof(real);
+    const __amdgpu_buffer_rsrc_t v_rsrc = buffer_rsrc(v, (size_t)T * KP * sizeof(real));
+    const __amdgpu_buffer_rsrc_t r_rsrc = buffer_rsrc(FUSE_DIR ? rvec : v, (size_t)T * KP * sizeof(real));
+    const int vbyte0 = ((i0 - Hh) * KP + tid) * sz;          // wraps below zero for the first tiles: reads 0
+    real vr[kHvOperandRegs], rv[kHvOperandRegs];
+#pragma unroll
+    for (int m = 0; m < kHvOperandRegs; m++) {
+        vr[m] = buffer_load_real(v_rsrc, vbyte0 + 256 * m * sz);
+        if (FUSE_DIR) rv[m] = buffer_load_real(r_rsrc, vbyte0 + 256 * m * sz);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (b) the thread's slice of the cached Gram: columns [t0, t0+VEC) of timestamp row i0+lr, all KQ rows
+    const int tpr = (k + VEC - 1) / VEC;
+    const int lr = tid / tpr, t0 = (tid - lr * tpr) * VEC;
+    const bool lane_on = lr < TI;
+    const int lrc = lane_on ? lr : TI - 1;                  // idle lanes shadow a live one (no branches)
+    // The first KA Gram rows (<= 128 registers) are requested here; the rest right after phase 1, when the
+    // operand registers are free again (a full 160-register slice next to them does not fit 256).
+    constexpr int KA = (KQ * VEC * (int)sizeof(real) / 4 <= 128) ? KQ : 128 / (VEC * (int)sizeof(real) / 4);
+    GramVec<VEC> gq[KQ];
+    const __amdgpu_buffer_rsrc_t g_rsrc = buffer_rsrc(G + (size_t)i0 * p.gstride, 0x7fffffff);
+    const int g_voff = (int)(((uint32_t)(min(i0 + lrc, T - 1) - i0) * (uint32_t)p.gstride + (uint32_t)t0) * sizeof(real));
+    const int rowbytes = k * (int)sizeof(real);
+    int g_soff = 0;
+#pragma unroll
+    for (int j = 0; j < KA; j++) {
+        gq[j] = gram_load<VEC>(g_rsrc, g_voff, g_soff);
+        g_soff += (j + 1 < k) ? rowbytes : 0;               // j >= k: a finite duplicate, multiplied by a zero pad
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // keep the requests above everything that follows
+
+    // (1) operand rows -> LDS (zero outside [0,T)); FUSE_DIR: d_new = d + (beta-1) d + r
     double ar2 = 0, vv = 0, dot = 0, lq = 0;
-    const int ntiles = (T + TI - 1) / TI;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int i0 = tile * TI, i1 = min(i0 + TI, T);
-        __syncthreads();
-        // (1) operand rows -> LDS (zero outside [0,T)); FUSE_DIR: d_new = d + (beta-1) d + r
-        for (int e = threadIdx.x; e < rowsV * KP; e += 256) {
-            const int rr = e / KP, t = e - rr * KP, i = i0 - Hh + rr;
-            real x = 0;
-            if (i >= 0 && i < T) {
-                x = v[(size_t)i * KP + t];
-                if (FUSE_DIR) { x = fma(tmp, x, x); x = x + rvec[(size_t)i * KP + t]; }
-                if (i >= i0 && i < i1) {
-                    if (FUSE_DIR) dnew[(size_t)i * KP + t] = x;
-                    vv += (double)x * (double)x;
+    const __amdgpu_buffer_rsrc_t d_rsrc = buffer_rsrc(FUSE_DIR ? dnew + (size_t)i0 * KP : nullptr,
+                                                      FUSE_DIR ? (size_t)(i1 - i0) * KP * sizeof(real) : 0);
+    const uint32_t own_n = (uint32_t)((i1 - i0) * KP);
+    auto operand = [&](int e, real x, real rx) {
+        if (FUSE_DIR) { x = fma(tmp, x, x); x = x + rx; }                  // zeros stay zero
+        const int eo = e - Hh * KP;                                        // index within the tile's own rows
+        if (FUSE_DIR) buffer_store_real(d_rsrc, eo * sz, x);               // dropped outside them
+        if ((uint32_t)eo < own_n) vv += (double)x * (double)x;
+        if (e < nV) vs[e] = x;
+    };
+#pragma unroll
+    for (int m = 0; m < kHvOperandRegs; m++) operand(tid + 256 * m, vr[m], FUSE_DIR ? rv[m] : real(0));
+#pragma nounroll
+    for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256)             // very long halos only
+        operand(e, buffer_load_real(v_rsrc, vbyte0 + (e - tid) * sz),
+                FUSE_DIR ? buffer_load_real(r_rsrc, vbyte0 + (e - tid) * sz) : real(0));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = KA; j < KQ; j++) {                         // rest of the Gram slice: lands during phase 2
+        gq[j] = gram_load<VEC>(g_rsrc, g_voff, g_soff);
+        g_soff += (j + 1 < k) ? rowbytes : 0;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const bool ar_on = nlag > 0 && p.lambdaAR > 0;
+    __syncthreads();
+    // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139)
+#pragma nounroll
+    for (int e = tid; e < rowsR * KP; e += 256) {
+        const int rr = e / KP, c = e - rr * KP, i = i0 + rr;                // c: position, tl: logical column
+        const int tl = collog(c, NT_T);
+        double res = 0;
+        if (ar_on && tl < k && i >= Hh && i < T) {
+            res = (double)vs[(rr + Hh) * KP + c];
+            for (int l = 0; l < nlag; l++) {
+                const real prod = ths[l * k + tl] * vs[(rr + Hh - lags[l]) * KP + c];
+                res -= (double)prod;
+            }
+            if (rr < TI) ar2 += res * res;
+        }
+        rs[e] = res;
+    }
+    __syncthreads();
+    // (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b) for the thread's row and VEC columns
+    {
+        const int rr = lrc, i = i0 + rr;
+        const bool live = lane_on && i < T;
+        const real *vi = vs + (rr + Hh) * KP;
+        int tcol[VEC], tpos[VEC];
+        real x[VEC], o[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; c++) {
+            tcol[c] = min(t0 + c, k - 1);
+            tpos[c] = colpos(tcol[c], NT_T);
+            x[c] = vi[tpos[c]];
+            if (p.lambdaI == 0) o[c] = 0;
+            else if (p.lambdaI == 1) o[c] = x[c];
+            else o[c] = (real)(p.lambdaI * (double)x[c]);
+        }
+        if (ar_on) {
+            if (i >= Hh) {
+#pragma unroll
+                for (int c = 0; c < VEC; c++) o[c] = (real)((double)o[c] + p.lambdaAR * rs[rr * KP + tpos[c]]);
+            }
+#pragma nounroll
+            for (int l = 0; l < nlag; l++) {
+                const int lg = lags[l], ii = i + lg;
+                if (ii >= Hh && ii < T) {
+#pragma unroll
+                    for (int c = 0; c < VEC; c++)
+                        o[c] = (real)((double)o[c] - p.lambdaAR * rs[(rr + lg) * KP + tpos[c]] * (double)ths[l * k + tcol[c]]);
                 }
             }
-            vs[e] = x;
         }
-        __syncthreads();
-        // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139)
-        for (int e = threadIdx.x; e < rowsR * KP; e += 256) {
-            const int rr = e / KP, tp = e - rr * KP, i = i0 + rr;         // tp: position, t: logical column
-            const int t = collog(tp, NT_T);
-            double res = 0;
-            if (ar_on && t < k && i >= Hh && i < T) {
-                res = (double)vs[(rr + Hh) * KP + tp];
-                for (int l = 0; l < nlag; l++) {
-                    const real prod = ths[t * nlag + l] * vs[(rr + Hh - lags[l]) * KP + tp];
-                    res -= (double)prod;
-                }
-                if (rr < TI) ar2 += res * res;
+        // cached Gram last: by now the slice has (mostly) arrived.  Four Gram rows per step; the operand
+        // values of the next step are read from LDS while this step's FMAs run.  The empty asm statements
+        // are ordering fences on VALUES (accumulators, the prefetched operands, the LDS pointer): without
+        // them the scheduler hoists every LDS read and conversion of the 40-row loop to the top and the
+        // register file -- most of which the slice already holds -- overflows into scratch.
+        double acc[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; c++) acc[c] = 0;
+        const real *vip = vi;
+        real vcur[4], vnext[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) vcur[u] = vip[colpos(u, NT_T)];  // logical column j sits at position colpos(j)
+#pragma unroll
+        for (int j0 = 0; j0 < KQ; j0 += 4) {
+            asm volatile("" : "+v"(vip));
+            if (j0 + 4 < KQ) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) vnext[u] = vip[colpos(j0 + 4 + u, NT_T)];
             }
-            rs[e] = res;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const double vj = (double)vcur[u];                          // pad columns hold 0
+#pragma unroll
+                for (int c = 0; c < VEC; c++) acc[c] += (double)gq[j0 + u].c[c] * vj;
+            }
+#pragma unroll
+            for (int c = 0; c < VEC; c++) asm volatile("" : "+v"(acc[c]));
+            if (j0 + 4 < KQ) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) { asm volatile("" : "+v"(vnext[u])); vcur[u] = vnext[u]; }
+            }
         }
-        __syncthreads();
-        // (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b), `rpb` rows per pass.  The cached Gram is the
-        //     only HBM-sized stream of the CG: kGChunk loads are kept in flight per thread.
-        const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;   // t: logical column
-        const int tp = colpos(t, NT_T);
-        for (int r0 = 0; r0 < TI; r0 += rpb) {
-            const int rr = r0 + lr, i = i0 + rr;
-            if (lr < rpb && rr < TI && i < T) {
-                const real x = vs[(rr + Hh) * KP + tp];
-                const real *Gi = G + (size_t)i * p.gstride + t;
-                const real *vi = vs + (rr + Hh) * KP;
-                double acc = 0;
-// logical column s2 = 16q + c sits at position NT*c + q: two constant-stride loops
-                for (int q = 0; q < NT_T; q++) {
-                    const int cn = min(kTile, k - kTile * q);
-                    const real *Gq = Gi + (size_t)(kTile * q) * k;
-                    const real *vq = vi + q;
-#pragma unroll 8
-                    for (int c2 = 0; c2 < cn; c2++) acc += (double)Gq[(size_t)c2 * k] * (double)vq[c2 * NT_T];
-                }
-                real o;
-                if (p.lambdaI == 0) o = 0;
-                else if (p.lambdaI == 1) o = x;
-                else o = (real)(p.lambdaI * (double)x);
-                if (ar_on) {
-                    if (i >= Hh) o = (real)((double)o + p.lambdaAR * rs[rr * KP + tp]);
-                    for (int l = 0; l < nlag; l++) {
-                        const int ii = i + lags[l];
-                        if (ii >= Hh && ii < T)
-                            o = (real)((double)o - p.lambdaAR * rs[(rr + lags[l]) * KP + tp] * (double)ths[t * nlag + l]);
-                    }
-                }
+#pragma unroll
+        for (int c = 0; c < VEC; c++) {
+            if (live && t0 + c < k) {
+                double a = acc[c];
                 if (GRAD) {
-                    const double bb = (double)Bv[(size_t)i * KP + t];
-                    lq += (double)x * (acc - 2.0 * bb);                      // w.(Gw) - 2 b.w
-                    acc -= bb;
+                    const double bb = (double)Bv[(size_t)i * KP + tcol[c]];
+                    lq += (double)x[c] * (a - 2.0 * bb);                     // w.(Gw) - 2 b.w
+                    a -= bb;
                 }
-                o = (real)((double)o + acc);
-                out[(size_t)i * KP + tp] = o;
-                dot += (double)(GRAD ? o : x) * (double)o;     // <g,g> for the gradient, <v,Hv> otherwise
+                const real oc = (real)((double)o[c] + a);
+                out[(size_t)i * KP + tpos[c]] = oc;
+                dot += (double)(GRAD ? oc : x[c]) * (double)oc;      // <g,g> for the gradient, <v,Hv> otherwise
             }
         }
     }
     block_allsum3(ar2, vv, dot, smem);
     if (GRAD) {
         lq = block_allsum(lq, smem);
-        if (threadIdx.x == 0) Pbase[P_LQ * kMaxPartials + blockIdx.x] = lq;
+        if (threadIdx.x == 0) Pbase[P_LQ * (size_t)p.pstride + blockIdx.x] = lq;
     }
     if (threadIdx.x == 0) {
-        Pbase[P_AR * kMaxPartials + blockIdx.x] = ar2;
-        Pbase[P_VV * kMaxPartials + blockIdx.x] = vv;
-        Pbase[P_DOT * kMaxPartials + blockIdx.x] = dot;
+        Pbase[P_AR * (size_t)p.pstride + blockIdx.x] = ar2;
+        Pbase[P_VV * (size_t)p.pstride + blockIdx.x] = vv;
+        Pbase[P_DOT * (size_t)p.pstride + blockIdx.x] = dot;
     }
 }
 
@@ -387,13 +539,13 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
                                                       real *__restrict__ s, real *__restrict__ r,
                                                       real *__restrict__ d) {
     __shared__ double smem[256];
-    const double ar2 = sum_partials(Pbase + P_AR * kMaxPartials, np_base, smem);
-    const double vv = sum_partials(Pbase + P_VV * kMaxPartials, np_base, smem);
-    const double gg = sum_partials(Pbase + P_DOT * kMaxPartials, np_dot, smem);
-    const double lq = p.full ? sum_partials(Pbase + P_LQ * kMaxPartials, np_dot, smem) : 0.0;
+    const double ar2 = sum_partials(Pbase + P_AR * (size_t)p.pstride, np_base, smem);
+    const double vv = sum_partials(Pbase + P_VV * (size_t)p.pstride, np_base, smem);
+    const double gg = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
+    const double lq = p.full ? sum_partials(Pbase + P_LQ * (size_t)p.pstride, np_dot, smem) : 0.0;
     const real ggr = (real)gg;                                               // BLAS dot in val_type
     // rho[0] = r^T r = g^T g (rf_tron.h:439), published as a one-hot partial array
-    if (threadIdx.x == 0) Pbase[P_RR0 * kMaxPartials + blockIdx.x] = (blockIdx.x == 0) ? (double)ggr : 0.0;
+    if (threadIdx.x == 0) Pbase[P_RR0 * (size_t)p.pstride + blockIdx.x] = (blockIdx.x == 0) ? (double)ggr : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // sparse path: loss0 = sum of squared residuals (gram_x_kernel); full path: trmf.cpp:189-197
         double f = p.full ? 0.5 * (p.trYTY + lq) : 0.5 * st->loss0;
@@ -470,8 +622,8 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const real *__rest
     gs = block_allsum(gs, smem);
     sr = block_allsum(sr, smem);
     if (threadIdx.x == 0) {
-        Pbase[P_GS * kMaxPartials + blockIdx.x] = gs;
-        Pbase[P_SR * kMaxPartials + blockIdx.x] = sr;
+        Pbase[P_GS * (size_t)p.pstride + blockIdx.x] = gs;
+        Pbase[P_SR * (size_t)p.pstride + blockIdx.x] = sr;
     }
 }
 
@@ -487,9 +639,9 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
                                                      const real *__restrict__ w_new,
                                                      real *__restrict__ w) {
     __shared__ double smem[256];
-    const double gs = (double)(real)sum_partials(Pbase + P_GS * kMaxPartials, np, smem);
-    const double sr = (double)(real)sum_partials(Pbase + P_SR * kMaxPartials, np, smem);
-    const double sHs = sum_partials(Pbase + P_DOT * kMaxPartials, np_dot, smem);
+    const double gs = (double)(real)sum_partials(Pbase + P_GS * (size_t)p.pstride, np, smem);
+    const double sr = (double)(real)sum_partials(Pbase + P_SR * (size_t)p.pstride, np, smem);
+    const double sHs = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
     const double rho = (double)(real)sum_partials(Prr_final, np, smem);
     const double f = st->f;
     const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190

@@ -101,7 +101,7 @@ struct TrmfSessionImpl {
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    double *P(int slot) { return partials.p + (size_t)slot * kMaxPartials; }
+    double *P(int slot) { return partials.p + (size_t)slot * xp.pstride; }
 
     // ---------------------------------------------------------------------------------------------
     // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).
@@ -177,14 +177,14 @@ struct TrmfSessionImpl {
         const size_t NV = (size_t)T * KP;
         if (full) {
             const size_t big = (size_t)std::max(T, n);
-            if (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k) ||
+            if (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
                 sgram_part.alloc((size_t)kSmallGramBlocks * k * k) ||
                 (dense && gemm_part.alloc((size_t)kGemmChunks * big * KP)))
                 return kFail;
         }
-        if (G.alloc(full ? 1 : (size_t)T * k * k) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
+        if (G.alloc((full ? 1 : (size_t)T * k * k) + kHvGramPad) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
             d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
-            lossrow.alloc(T) || partials.alloc((size_t)P_NSLOTS * kMaxPartials) || xstate.alloc(1) ||
+            lossrow.alloc(T) || xstate.alloc(1) ||
             log.alloc(kLogCap))
             return kFail;
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
@@ -194,13 +194,15 @@ struct TrmfSessionImpl {
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
         nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
-        {   // fused Hv tile: two passes of `rpb` rows, if the AR halo fits a modest LDS budget
-            const int TI = 2 * rpb;
+        {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
+            const int TI = hv_tile_rows(k);
             if (hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
                 tile_TI = TI;
-                nbt = std::min(kMaxPartials, (T + TI - 1) / TI);
+                nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
         }
+        xp.pstride = std::max(kMaxPartials, nbt);
+        if (partials.alloc((size_t)P_NSLOTS * xp.pstride)) return kFail;
         xp.T = T; xp.k = k; xp.KP = KP; xp.NT = NT; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
         xp.full = full ? 1 : 0; xp.gstride = full ? 0 : (size_t)k * k; xp.trYTY = trYTY;
@@ -452,20 +454,24 @@ struct TrmfSessionImpl {
         double *Pb = partials.p;
         if (tile_TI > 0) {
             const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
-#define TRMF_LAUNCH_HV_NT(FUSE, GRAD, NTT)                                                              \
-            hipLaunchKernelGGL((hv_tile_kernel<FUSE, GRAD, NTT>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur,  \
-                               Pprev, nbe, v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, out, Pb, tile_TI, rpb)
+#define TRMF_LAUNCH_HV_KQ(FUSE, GRAD, KQ)                                                               \
+            hipLaunchKernelGGL((hv_tile_kernel<FUSE, GRAD, KQ>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur,   \
+                               Pprev, nbe, v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, out, Pb, tile_TI)
 #define TRMF_LAUNCH_HV(FUSE, GRAD)                                                                      \
-            switch (NT) {                                                                               \
-                case 1: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 1); break;                                         \
-                case 2: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 2); break;                                         \
-                case 3: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 3); break;                                         \
-                default: TRMF_LAUNCH_HV_NT(FUSE, GRAD, 4); break;                                        \
+            switch (hv_kq(k) / 8) {                                                                      \
+                case 1: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 8); break;                                         \
+                case 2: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 16); break;                                        \
+                case 3: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 24); break;                                        \
+                case 4: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 32); break;                                        \
+                case 5: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 40); break;                                        \
+                case 6: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 48); break;                                        \
+                case 7: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 56); break;                                        \
+                default: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 64); break;                                       \
             }
             if (fuse) { TRMF_LAUNCH_HV(true, false); }
             else if (minus_b) { TRMF_LAUNCH_HV(false, true); }
             else { TRMF_LAUNCH_HV(false, false); }
-#undef TRMF_LAUNCH_HV_NT
+#undef TRMF_LAUNCH_HV_KQ
 #undef TRMF_LAUNCH_HV
         } else {
             if (fuse)
