@@ -255,9 +255,10 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
 __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, int nlag = 0, int k = 0) {
     const size_t a = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;
     const size_t b = ((size_t)(TI + midx) * KP * sizeof(double) + 15) / 16 * 16;
-    return a + b + (size_t)nlag * k * sizeof(real) + (size_t)nlag * sizeof(int);   // + Theta, lag_set
+    return a + b + (size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)nlag * sizeof(int);  // + lambdaAR*Theta, Theta, lag_set
 }
 constexpr int kHvThetaRegs = 3;                  // Theta elements per thread loaded ahead of the scalar prologue
+constexpr int kHvResU = 2;                       // AR residual work items (4 columns each) a thread carries through the lag loop
 constexpr int kHvOperandRegs = 12;               // operand elements per thread requested ahead of the Gram
 constexpr int kHvGramPad = 4;                    // elements allocated past the Gram cache (vector tail reads)
 // Gram columns per thread: one 16-byte load per Gram row up to rank 40, 8-byte loads above (the thread's
@@ -287,8 +288,14 @@ __device__ __forceinline__ void buffer_store_real(__amdgpu_buffer_rsrc_t rsrc, i
     }
 }
 template <int VEC> struct GramVec { real c[VEC]; };
+// aligned packs for vector LDS access (ds_read_b64 / ds_read_b128)
+template <typename T> struct alignas(16) Quad { T v[4]; };
+template <typename T, int N> struct alignas((N * sizeof(T)) % 16 == 0 ? 16 : 8) VecOf { T v[N]; };
 template <int VEC>
 __device__ __forceinline__ GramVec<VEC> gram_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+#if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 1)
+    GramVec<VEC> z; for (int c = 0; c < VEC; c++) z.c[c] = (real)voff; return z;
+#endif
     if constexpr (VEC * sizeof(real) == 16)
         return __builtin_bit_cast(GramVec<VEC>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
     else
@@ -322,8 +329,12 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
     const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T);   // one tile per workgroup
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
-    real *ths = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
-    int *lags = reinterpret_cast<int *>(ths + (size_t)nlag * k);
+    double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
+    real *thp = reinterpret_cast<real *>(thd + (size_t)nlag * KP);
+    int *lags = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
+    // thd[l*KP + t]   = lambdaAR * Theta(l,t) in double, LOGICAL column order  (AR adjoint, phase 3)
+    // thp[l*KP + pos] = Theta(l, collog(pos)), POSITION order like the staged operand  (AR residual, phase 2)
+    // both with the row stride KP so that a thread's 4 neighbouring columns are one aligned 16/32-byte read
 
     // ---- scalar prologue: rho, stop test, beta; Theta / lag set to LDS (their loads fly with the partials) ----
     real thr[kHvThetaRegs];
@@ -334,6 +345,9 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
         lagr = (int)lag_set[min(tid, nlag - 1)];
     }
     real tmp = 0;
+#if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 4)
+    tmp = (real)0.25;
+#else
     if (Prr_cur != nullptr) {
         if (FUSE_DIR) {
             double s_cur, s_prev;
@@ -347,16 +361,23 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
             if (cg_stopped(rho, st->cgtol)) return;
         }
     }
-    if (nlag > 0) {                                         // Theta(l,t) at ths[l*k+t]: lanes over t, distinct banks
-#pragma unroll
-        for (int m = 0; m < kHvThetaRegs; m++) {
-            const int e = tid + 256 * m, tt = e / nlag, l = e - tt * nlag;
-            if (e < nTh) ths[l * k + tt] = thr[m];
-        }
-#pragma nounroll
-        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) {
+#endif
+    if (nlag > 0) {
+        auto put = [&](int e, real th) {
             const int tt = e / nlag, l = e - tt * nlag;
-            ths[l * k + tt] = theta[e];
+            thp[l * KP + colpos(tt, NT_T)] = th;
+            thd[l * KP + tt] = p.lambdaAR * (double)th;
+        };
+#pragma unroll
+        for (int m = 0; m < kHvThetaRegs; m++)
+            if (tid + 256 * m < nTh) put(tid + 256 * m, thr[m]);
+#pragma nounroll
+        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) put(e, theta[e]);
+#pragma nounroll
+        for (int e = tid; e < nlag * (KP - k); e += 256) {                  // pad columns: exact zeros
+            const int l = e / (KP - k), tt = k + (e - l * (KP - k));
+            thp[l * KP + colpos(tt, NT_T)] = 0;
+            thd[l * KP + tt] = 0;
         }
         if (tid < nlag) lags[tid] = lagr;
 #pragma nounroll
@@ -383,8 +404,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
     const int lr = tid / tpr, t0 = (tid - lr * tpr) * VEC;
     const bool lane_on = lr < TI;
     const int lrc = lane_on ? lr : TI - 1;                  // idle lanes shadow a live one (no branches)
-    // The first KA Gram rows (<= 128 registers) are requested here; the rest right after phase 1, when the
-    // operand registers are free again (a full 160-register slice next to them does not fit 256).
+    // The first KA Gram rows (<= 128 registers) are requested here; the rest after phase 2 (a full 160-register slice next to them does not fit 256).
     constexpr int KA = (KQ * VEC * (int)sizeof(real) / 4 <= 128) ? KQ : 128 / (VEC * (int)sizeof(real) / 4);
     GramVec<VEC> gq[KQ];
     const __amdgpu_buffer_rsrc_t g_rsrc = buffer_rsrc(G + (size_t)i0 * p.gstride, 0x7fffffff);
@@ -416,31 +436,73 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
     for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256)             // very long halos only
         operand(e, buffer_load_real(v_rsrc, vbyte0 + (e - tid) * sz),
                 FUSE_DIR ? buffer_load_real(r_rsrc, vbyte0 + (e - tid) * sz) : real(0));
+#if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 2)
+    const bool ar_on = false;
+#else
+    const bool ar_on = nlag > 0 && p.lambdaAR > 0;
+#endif
+    __syncthreads();
+    // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139), stored to rs in LOGICAL
+    //     column order.  A work item is (row, 4 neighbouring positions): per lag it costs two 16-byte LDS
+    //     reads (operand, Theta in position order) for four residuals; kHvResU items advance together.
+    if (ar_on) {
+        constexpr int NG = KP / 4;
+        const int items = rowsR * NG;
+#pragma nounroll
+        for (int it0 = 0; it0 < items; it0 += 256 * kHvResU) {
+            int vb[kHvResU], pg[kHvResU];
+            bool on[kHvResU];
+            double res[kHvResU][4];
+#pragma unroll
+            for (int u = 0; u < kHvResU; u++) {
+                const int it = it0 + tid + 256 * u;
+                const int rr = it / NG, g = it - rr * NG, i = i0 + rr;
+                on[u] = it < items && i >= Hh && i < T;
+                vb[u] = on[u] ? (rr + Hh) * KP + 4 * g : Hh * KP;
+                pg[u] = on[u] ? 4 * g : 0;
+                const Quad<real> x4 = *reinterpret_cast<const Quad<real> *>(vs + vb[u]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) res[u][c] = (double)x4.v[c];
+            }
+#pragma unroll 2
+            for (int l = 0; l < nlag; l++) {
+                const int back = lags[l] * KP;
+                const real *thl = thp + l * KP;
+#pragma unroll
+                for (int u = 0; u < kHvResU; u++) {
+                    const Quad<real> th4 = *reinterpret_cast<const Quad<real> *>(thl + pg[u]);
+                    const Quad<real> x4 = *reinterpret_cast<const Quad<real> *>(vs + vb[u] - back);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        const real prod = th4.v[c] * x4.v[c];
+                        res[u][c] -= (double)prod;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kHvResU; u++) {
+                const int it = it0 + tid + 256 * u;
+                const int rr = it / NG, g = it - rr * NG;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int tl = collog(4 * g + c, NT_T);
+                    const double rv2 = on[u] ? res[u][c] : 0.0;           // rows outside [midx,T): exact zeros
+                    if (it < items && tl < k) {
+                        if (rr < TI) ar2 += rv2 * rv2;
+                        rs[rr * KP + tl] = rv2;
+                    }
+                }
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = KA; j < KQ; j++) {                         // rest of the Gram slice: lands during phase 2
+    for (int j = KA; j < KQ; j++) {                         // rest of the Gram slice: requested only now -- phase 2 needs the registers for its
+                                                            // independent LDS reads -- and lands under the AR adjoint
         gq[j] = gram_load<VEC>(g_rsrc, g_voff, g_soff);
         g_soff += (j + 1 < k) ? rowbytes : 0;
     }
     __builtin_amdgcn_sched_barrier(0);
-    const bool ar_on = nlag > 0 && p.lambdaAR > 0;
-    __syncthreads();
-    // (2) AR residuals of rows [i0, i0+TI+midx)  (trmf.cpp:110-113 / 136-139)
-#pragma nounroll
-    for (int e = tid; e < rowsR * KP; e += 256) {
-        const int rr = e / KP, c = e - rr * KP, i = i0 + rr;                // c: position, tl: logical column
-        const int tl = collog(c, NT_T);
-        double res = 0;
-        if (ar_on && tl < k && i >= Hh && i < T) {
-            res = (double)vs[(rr + Hh) * KP + c];
-            for (int l = 0; l < nlag; l++) {
-                const real prod = ths[l * k + tl] * vs[(rr + Hh - lags[l]) * KP + c];
-                res -= (double)prod;
-            }
-            if (rr < TI) ar2 += res * res;
-        }
-        rs[e] = res;
-    }
     __syncthreads();
     // (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b) for the thread's row and VEC columns
     {
@@ -448,29 +510,33 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
         const bool live = lane_on && i < T;
         const real *vi = vs + (rr + Hh) * KP;
         int tcol[VEC], tpos[VEC];
-        real x[VEC], o[VEC];
+        real x[VEC];
+        double od[VEC];                                     // lambdaI*v + lambdaAR*AR'(v), carried in double
 #pragma unroll
         for (int c = 0; c < VEC; c++) {
             tcol[c] = min(t0 + c, k - 1);
             tpos[c] = colpos(tcol[c], NT_T);
             x[c] = vi[tpos[c]];
-            if (p.lambdaI == 0) o[c] = 0;
-            else if (p.lambdaI == 1) o[c] = x[c];
-            else o[c] = (real)(p.lambdaI * (double)x[c]);
+            real o;
+            if (p.lambdaI == 0) o = 0;
+            else if (p.lambdaI == 1) o = x[c];
+            else o = (real)(p.lambdaI * (double)x[c]);
+            od[c] = (double)o;
         }
         if (ar_on) {
-            if (i >= Hh) {
+            // residual rows outside [midx, T) were stored as exact zeros by phase 2, so neither the own-row
+            // term nor the lagged terms need a range test; lambdaAR*Theta comes pre-multiplied from LDS
+            {
+                const VecOf<double, VEC> r0 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + rr * KP + t0);
 #pragma unroll
-                for (int c = 0; c < VEC; c++) o[c] = (real)((double)o[c] + p.lambdaAR * rs[rr * KP + tpos[c]]);
+                for (int c = 0; c < VEC; c++) od[c] += p.lambdaAR * r0.v[c];
             }
-#pragma nounroll
-            for (int l = 0; l < nlag; l++) {
-                const int lg = lags[l], ii = i + lg;
-                if (ii >= Hh && ii < T) {
+#pragma unroll 4
+            for (int l = 0; l < nlag; l++) {                // VEC neighbouring logical columns: aligned vector reads
+                const VecOf<double, VEC> r4 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + (rr + lags[l]) * KP + t0);
+                const VecOf<double, VEC> t4 = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
 #pragma unroll
-                    for (int c = 0; c < VEC; c++)
-                        o[c] = (real)((double)o[c] - p.lambdaAR * rs[(rr + lg) * KP + tpos[c]] * (double)ths[l * k + tcol[c]]);
-                }
+                for (int c = 0; c < VEC; c++) od[c] -= r4.v[c] * t4.v[c];
             }
         }
         // cached Gram last: by now the slice has (mostly) arrived.  Four Gram rows per step; the operand
@@ -514,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
                     lq += (double)x[c] * (a - 2.0 * bb);                     // w.(Gw) - 2 b.w
                     a -= bb;
                 }
-                const real oc = (real)((double)o[c] + a);
+                const real oc = (real)(od[c] + a);
                 out[(size_t)i * KP + tpos[c]] = oc;
                 dot += (double)(GRAD ? oc : x[c]) * (double)oc;      // <g,g> for the gradient, <v,Hv> otherwise
             }
