@@ -172,7 +172,8 @@ def main():
             torch.cuda.synchronize()
 
     t_up = time.perf_counter()
-    s = session.Session(prob['Y'], model, missing=missing, **hyper)
+    # verbose=0 run of the reference: no ||.||^2 log lines (trmf.cpp:659-688 evaluates them only under verbose)
+    s = session.Session(prob['Y'], model, missing=missing, log_norms=False, **hyper)
     t_up = time.perf_counter() - t_up
     s.run(args.warmup)
     device_sync(s); barrier()

@@ -608,13 +608,15 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
     const double ar2 = sum_partials(Pbase + P_AR * (size_t)p.pstride, np_base, smem);
     const double vv = sum_partials(Pbase + P_VV * (size_t)p.pstride, np_base, smem);
     const double gg = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
-    const double lq = p.full ? sum_partials(Pbase + P_LQ * (size_t)p.pstride, np_dot, smem) : 0.0;
+    const double lq = sum_partials(Pbase + P_LQ * (size_t)p.pstride, np_dot, smem);
     const real ggr = (real)gg;                                               // BLAS dot in val_type
     // rho[0] = r^T r = g^T g (rf_tron.h:439), published as a one-hot partial array
     if (threadIdx.x == 0) Pbase[P_RR0 * (size_t)p.pstride + blockIdx.x] = (blockIdx.x == 0) ? (double)ggr : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        // sparse path: loss0 = sum of squared residuals (gram_x_kernel); full path: trmf.cpp:189-197
-        double f = p.full ? 0.5 * (p.trYTY + lq) : 0.5 * st->loss0;
+        // loss = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i): the reference's own formula on the full path
+        // (trmf.cpp:189-197); on the observed-entries path the same identity over the cached Grams replaces its
+        // pass over the residuals (trmf.cpp:231-245) -- f only feeds the TRON line, not the iterates
+        double f = 0.5 * (p.trYTY + lq);
         if (p.lambdaI > 0) f += 0.5 * p.lambdaI * (double)(real)vv;          // trmf.cpp:73-75
         if (p.nlag > 0 && p.lambdaAR > 0) f += 0.5 * p.lambdaAR * ar2;       // trmf.cpp:94
         const double gnorm = sqrt((double)ggr);

@@ -751,13 +751,11 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
                                                      const real *__restrict__ Hf,
                                                      const real *__restrict__ W,
                                                      real *__restrict__ G, real *__restrict__ Bv,
-                                                     double *__restrict__ lossrow,
                                                      uint32_t row_begin, uint32_t row_end, int k,
                                                      uint32_t zero_row) {
     constexpr int KP = kTile * NT, LD = KP + 1;
     __shared__ real S[KP * LD];
     __shared__ real Sb[KP];
-    __shared__ double Sl[4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = row_begin + blockIdx.x;
@@ -773,17 +771,16 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
         const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p0 + 4u * (uint32_t)wave));
         const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
         GramDesc d0{e0, e1, e0 < e1 ? 0 : -1};
-        gram_ring<NT, kRingDepth, true, true>(st, idx, val, Hf, zero_row, 16u, lane, wq, d0,
-                                              SingleRowStream{16u * kRingDepth}, [](int) {});
+        // no per-entry residual here: the loss at w comes out of the gradient kernel as
+        // sum(y^2) + sum_i (w_i^T G_i w_i - 2 b_i.w_i)  (cg_init_kernel), ten VALU instructions per group cheaper
+        gram_ring<NT, kRingDepth, true, false>(st, idx, val, Hf, zero_row, 16u, lane, wq, d0,
+                                               SingleRowStream{16u * kRingDepth}, [](int) {});
     }
 #pragma unroll
     for (int q = 0; q < NT; q++) {
         st.b[q] += __shfl_xor(st.b[q], 16, kWave);
         st.b[q] += __shfl_xor(st.b[q], 32, kWave);
     }
-    double l = (c == 0) ? st.loss : 0.0;               // every lane of a 16-row holds the same residual
-    l = wave_allsum(l);
-    if (lane == 0) Sl[wave] = l;
 
     for (int w = 0; w < 4; w++) {                       // ordered accumulation: deterministic
         if (wave == w) {
@@ -813,7 +810,6 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
         Grow[e] = (s <= t) ? S[s * LD + t] : S[t * LD + s];
     }
     if ((int)threadIdx.x < KP) Bv[(size_t)row * KP + threadIdx.x] = ((int)threadIdx.x < k) ? Sb[threadIdx.x] : real(0);
-    if (threadIdx.x == 0) lossrow[row] = (Sl[0] + Sl[1]) + (Sl[2] + Sl[3]);
 }
 
 // ---- loss only (f(w_new) of the TRON acceptance test, rf_tron.h:191) ------------------------------

@@ -66,6 +66,7 @@ struct TrmfSessionImpl {
     uint64_t nnz = 0;
     double lambdaI = 0, lambdaAR = 0, lambdaLag = 0;
     int period_W = 1, period_H = 1, period_Lag = 2, verbose = 0;
+    bool log_norms = true;       // ||.||^2 records of the iteration log (the reference: only under verbose)
     int max_cg_iter = 20;        // 10 * 2, trmf.h:90-93 folded by trmf.cpp:603-606
     double eps_cg = 0.1;
     int iter = 0;                // ALS iterations done so far
@@ -148,11 +149,13 @@ struct TrmfSessionImpl {
             if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
             if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
             if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
-            if (full) {
+            {
                 const real *v = (const real *)Y->val_t;
                 double acc = 0;
                 for (uint64_t e = 0; e < nnz; e++) acc += (double)v[e] * (double)v[e];
-                trYTY = (double)(real)acc;                                   // do_dot_product(Y, Y), trmf.cpp:184
+                // full: do_dot_product(Y, Y) in val_type (trmf.cpp:184); observed-entries path: kept in double,
+                // it is the constant of  loss(w) = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i)
+                trYTY = full ? (double)(real)acc : acc;
             }
         } else {
             // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC
@@ -346,7 +349,7 @@ struct TrmfSessionImpl {
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
         if (re > rb)
             hipLaunchKernelGGL((gram_x_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
-                               Yr_val.p, H.p, W.p, G.p, Bv.p, lossrow.p, rb, re, k, (uint32_t)n);
+                               Yr_val.p, H.p, W.p, G.p, Bv.p, rb, re, k, (uint32_t)n);
     }
     template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
         if (re > rb)
@@ -363,8 +366,7 @@ struct TrmfSessionImpl {
         }
         TRMF_HIP_CHECK(hipGetLastError());
         if (gather_rows(G.p, xbounds, (size_t)k * k * sizeof(real))) return kFail;
-        if (gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
-        return gather_rows(lossrow.p, xbounds, sizeof(double));
+        return gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real));
     }
     int loss(const real *Wv, bool all_rows) {
         const uint32_t rb = all_rows ? 0u : (uint32_t)xbounds[comm->rank];
@@ -495,8 +497,7 @@ struct TrmfSessionImpl {
         if (full) {
             if (xprepare_full()) return kFail;                                 // b = Y H, shared Gram H^T H
         } else {
-            if (gram_x()) return kFail;                                        // G, b, loss(w)
-            hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss0);
+            if (gram_x()) return kFail;                                        // G, b
         }
         hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0);           // gradient, <g,g>, AR/ridge sums
         hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, np_base(), np_dot(), g.p,
@@ -567,7 +568,7 @@ struct TrmfSessionImpl {
             const bool doL = period_Lag > 0 && (iter1 % period_Lag) == 0;
             if (doF) {
                 if (full ? fsolve_full(ev) : fsolve(ev)) return kFail;
-                log_norm(H.p, (size_t)n * KP, &L->normF);
+                if (log_norms || verbose) log_norm(H.p, (size_t)n * KP, &L->normF);
                 if (verbose) fprintf(stderr, ">> iter %d F %g\n", iter1, host_double(&L->normF));
             } else {
                 TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
@@ -576,7 +577,7 @@ struct TrmfSessionImpl {
             TRMF_HIP_CHECK(hipEventRecord(ev.f1, stream));
             if (doX) {
                 if (xsolve()) return kFail;
-                log_norm(W.p, (size_t)T * KP, &L->normX);
+                if (log_norms || verbose) log_norm(W.p, (size_t)T * KP, &L->normX);
                 TRMF_HIP_CHECK(hipMemcpyAsync(&L->x, xstate.p, sizeof(XState), hipMemcpyDeviceToDevice, stream));
                 if (verbose) {
                     fprintf(stderr, ">> iter %d X %g\n", iter1, host_double(&L->normX));
@@ -596,7 +597,7 @@ struct TrmfSessionImpl {
                     fprintf(stderr, ">> iter %d LV(%d %d) %g\n", iter1, nlag, k, host_double(&L->normLV));
                 }
                 if (theta_solve()) return kFail;
-                log_norm(theta.p, (size_t)nlag * k, &L->normLV);
+                if (log_norms || verbose) log_norm(theta.p, (size_t)nlag * k, &L->normLV);
                 if (verbose) fprintf(stderr, ">> iter %d LV %g\n", iter1, host_double(&L->normLV));
             }
             TRMF_HIP_CHECK(hipEventRecord(ev.lv1, stream));

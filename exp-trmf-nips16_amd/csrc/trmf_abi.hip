@@ -124,6 +124,7 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
     if (!warm_start) return;
     TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
                                       lambdaLag, period_W, period_H, period_Lag, missing, verbose);
+    if (s) s->log_norms = verbose > 0;       // the norm lines exist only under verbose (trmf.cpp:659-688)
     if (!s) return;                                  // diagnostics already on stderr; outputs untouched
     int rc = s->run(max_iter);
     if (rc == 0) rc = s->sync();
@@ -170,6 +171,11 @@ TrmfSession *trmf_session_create(const PyMatrix *Y, const uint32_t *lag_set, uin
 #define IMPL(s) reinterpret_cast<TrmfSessionImpl *>(s)
 
 int32_t trmf_session_run(TrmfSession *s, int32_t iters) { return s ? IMPL(s)->run(iters) : kFail; }
+int32_t trmf_session_log_norms(TrmfSession *s, int32_t on) {
+    if (!s) return kFail;
+    IMPL(s)->log_norms = on != 0;
+    return 0;
+}
 int32_t trmf_session_sync(TrmfSession *s) { return s ? IMPL(s)->sync() : kFail; }
 
 int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val) {

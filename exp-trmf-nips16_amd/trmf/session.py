@@ -42,6 +42,7 @@ def bind(lib):
                                         c_int32, c_int32, c_int32, c_int32, c_int32]
     lib.trmf_session_create.restype = c_void_p
     lib.trmf_session_run.argtypes = [c_void_p, c_int32]; lib.trmf_session_run.restype = c_int32
+    lib.trmf_session_log_norms.argtypes = [c_void_p, c_int32]; lib.trmf_session_log_norms.restype = c_int32
     lib.trmf_session_sync.argtypes = [c_void_p]; lib.trmf_session_sync.restype = c_int32
     lib.trmf_session_download.argtypes = [c_void_p, P, P, P]; lib.trmf_session_download.restype = c_int32
     lib.trmf_session_stats.argtypes = [c_void_p, POINTER(TrmfIterStats), c_int32]
@@ -70,7 +71,7 @@ class Session(object):
     """``Session(Y, model, **hyper).run(iters)``; the model's arrays are refreshed by ``download()``."""
 
     def __init__(self, Y, model, lambdaI=0.1, lambdaAR=0.1, lambdaLag=0.1,
-                 period_W=1, period_H=1, period_Lag=2, missing=True, verbose=0):
+                 period_W=1, period_H=1, period_Lag=2, missing=True, verbose=0, log_norms=True):
         self.model = model
         self.lib = lib_for(model.W.dtype)
         self.pyY = Y if isinstance(Y, PyMatrix) else PyMatrix(Y, dtype=model.W.dtype)
@@ -80,6 +81,8 @@ class Session(object):
             lambdaI, lambdaAR, lambdaLag, period_W, period_H, period_Lag, int(missing), verbose)
         if not self.handle:
             raise RuntimeError('trmf_session_create failed: ' + self.lib.trmf_last_error().decode())
+        if not log_norms:       # the reference computes the ||.||^2 log lines only under verbose
+            self.lib.trmf_session_log_norms(self.handle, 0)
 
     def _check(self, rc, what):
         if rc < 0:
