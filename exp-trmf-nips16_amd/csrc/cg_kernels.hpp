@@ -17,15 +17,22 @@
 
 namespace trmf {
 
+constexpr int kCgHistCap = 64;    // CG iterations the fused path can record (the reference folds to 20)
+
 struct XState {
     double f, fnew, gnorm, cg_rnorm, actred, prered, gs, sr;
     double loss0, loss1;          // sum of squared residuals at w and at w_new (reduce_rows_kernel)
     real cgtol;
     int cg_iter, accepted;
+    // fused CG path (hv_tile_kernel, HV_CG_*): r^T r of every iteration, stop flag, buffer that holds the final r
+    double rho_hist[kCgHistCap + 2];
+    int cg_done, r_parity;
 };
 
 // partial-sum arrays: Pbase[slot * kMaxPartials + block]
-enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_LQ = 7, P_NSLOTS = 8 };
+enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_LQ = 7,
+                   P_CG0 = 8,    // fused CG path: <d,Hd>, <r,Hd>, <Hd,Hd> of even iterations (P_CG0..+2), odd ones (+3..+5)
+                   P_NSLOTS = 14 };
 
 struct XParams {
     int T, k, KP, NT, nlag, midx;      // NT = KP/16: vectors use the column-interleaved layout (colpos)
@@ -255,7 +262,8 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
 __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, int nlag = 0, int k = 0) {
     const size_t a = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;
     const size_t b = ((size_t)(TI + midx) * KP * sizeof(double) + 15) / 16 * 16;
-    return a + b + (size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)nlag * sizeof(int);  // + lambdaAR*Theta, Theta, lag_set
+    const size_t c = ((size_t)TI * KP * sizeof(real) + 15) / 16 * 16;                                  // own-row r (fused CG)
+    return a + b + c + (size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)nlag * sizeof(int);  // + lambdaAR*Theta, Theta, lag_set
 }
 constexpr int kHvThetaRegs = 3;                  // Theta elements per thread loaded ahead of the scalar prologue
 constexpr int kHvResU = 2;                       // AR residual work items (4 columns each) a thread carries through the lag loop
@@ -302,24 +310,43 @@ __device__ __forceinline__ GramVec<VEC> gram_load(__amdgpu_buffer_rsrc_t rsrc, i
         return __builtin_bit_cast(GramVec<VEC>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
 }
 
-// GRAD: gradient call (subtracts b, emits the quadratic-loss partial of the full path); compile-time so that
-// the 20 Hessian-vector calls per solve carry none of it (measured: +0.3 ms per solve as a runtime flag).
+// One kernel, four roles (compile-time, so that the 20 CG launches carry nothing of the others; a runtime
+// flag in this kernel cost +0.3 ms per solve when measured):
+//   HV_PLAIN     out = H v,            partial <v, Hv>                     (H s of the acceptance test)
+//   HV_GRAD      out = H v - b,        partials <g,g>, AR/ridge sums, w.(Gw) - 2 b.w   (gradient at w)
+//   HV_CG_FIRST  CG iteration 0: f, |g|, cgtol (rf_tron.h:154-169, 424-439); s = 0, r = d = -g; out = H d
+//   HV_CG_STEP   CG iteration it >= 1, the WHOLE iteration in one launch (rf_tron.h:456-502):
+//                   alpha = rho/<d,Hd>;  s += alpha d;  r -= alpha Hd;            (closes iteration it-1)
+//                   rho' = rho - 2 alpha <r,Hd> + alpha^2 <Hd,Hd>                 (= r'^T r', no extra pass)
+//                   stop if sqrt(rho') <= cgtol, else beta = rho'/rho, d' = r' + beta d, out = H d'
+//                The three dot products come from the previous launch's per-tile partials (fixed order,
+//                double), so every workgroup -- and every rank -- derives the same scalars; r' on the halo
+//                rows is recomputed from r and Hd, nothing is exchanged.  `last` closes the final iteration.
 // KQ = rank rounded up to 8 (Gram rows requested per thread).
-template <bool FUSE_DIR, bool GRAD, int KQ>
-__global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState *__restrict__ st,
-                                                         const double *__restrict__ Prr_cur,
-                                                         const double *__restrict__ Prr_prev, int np,
-                                                         const real *__restrict__ v,
-                                                         const real *__restrict__ rvec,
-                                                         real *__restrict__ dnew,
+enum HvMode { HV_PLAIN = 0, HV_GRAD = 1, HV_CG_FIRST = 2, HV_CG_STEP = 3 };
+
+struct HvVecs {
+    const real *v;        // PLAIN/GRAD: operand;  CG_FIRST: gradient g;  CG_STEP: previous direction d
+    const real *r_in;     // CG_STEP: residual of the previous iteration
+    const real *hd_in;    // CG_STEP: H d of the previous iteration
+    real *s;              // CG_*: the step (own rows, in place)
+    real *d_out;          // CG_*: new direction
+    real *r_out;          // CG_*: new residual
+    real *out;            // H v / gradient / H d
+    const real *Bv;       // GRAD: right-hand sides
+};
+
+template <int MODE, int KQ>
+__global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, int np_in,
+                                                         int it, int last,
                                                          const uint32_t *__restrict__ lag_set,
                                                          const real *__restrict__ theta,
                                                          const real *__restrict__ G,
-                                                         const real *__restrict__ Bv,
-                                                         real *__restrict__ out,
                                                          double *__restrict__ Pbase, int TI) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
+    constexpr bool GRAD = MODE == HV_GRAD;
+    constexpr bool CG = MODE == HV_CG_FIRST || MODE == HV_CG_STEP;
     constexpr int VEC = hv_vec(KQ);
     constexpr int NT_T = (KQ + kTile - 1) / kTile;
     constexpr int KP = kTile * NT_T;
@@ -329,14 +356,18 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
     const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T);   // one tile per workgroup
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
-    double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
+    real *rn = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
+    double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rn) + (((size_t)TI * KP * sizeof(real) + 15) / 16 * 16));
     real *thp = reinterpret_cast<real *>(thd + (size_t)nlag * KP);
     int *lags = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
-    // thd[l*KP + t]   = lambdaAR * Theta(l,t) in double, LOGICAL column order  (AR adjoint, phase 3)
-    // thp[l*KP + pos] = Theta(l, collog(pos)), POSITION order like the staged operand  (AR residual, phase 2)
+    // rn[own row][pos]  = new residual of the tile's own rows (fused CG: <r,Hd>)
+    // thd[l*KP + t]     = lambdaAR * Theta(l,t) in double, LOGICAL column order  (AR adjoint, phase 3)
+    // thp[l*KP + pos]   = Theta(l, collog(pos)), POSITION order like the staged operand  (AR residual, phase 2)
     // both with the row stride KP so that a thread's 4 neighbouring columns are one aligned 16/32-byte read
 
-    // ---- scalar prologue: rho, stop test, beta; Theta / lag set to LDS (their loads fly with the partials) ----
+    if (MODE == HV_CG_STEP && st->cg_done) return;          // sticky stop: an earlier launch ended the CG
+
+    // ---- scalar prologue; Theta / lag set to LDS (their loads fly with the partials) ----
     real thr[kHvThetaRegs];
     int lagr = 0;
     if (nlag > 0) {
@@ -344,24 +375,55 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
         for (int m = 0; m < kHvThetaRegs; m++) thr[m] = theta[min(tid + 256 * m, nTh - 1)];
         lagr = (int)lag_set[min(tid, nlag - 1)];
     }
-    real tmp = 0;
-#if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 4)
-    tmp = (real)0.25;
-#else
-    if (Prr_cur != nullptr) {
-        if (FUSE_DIR) {
-            double s_cur, s_prev;
-            sum_partials2(Prr_cur, Prr_prev, np, s_cur, s_prev, smem);
-            const real rho = (real)s_cur, rho_prev = (real)s_prev;
-            if (cg_stopped(rho, st->cgtol)) return;
-            const real beta = rho / rho_prev;                                // rf_tron.h:495
-            tmp = beta - (real)1.0;                                          // rf_tron.h:497
-        } else {
-            const real rho = (real)sum_partials(Prr_cur, np, smem);
-            if (cg_stopped(rho, st->cgtol)) return;
+    real tmp = 0, alpha = 0, nalpha = 0;
+    bool stopped = false;
+    if (MODE == HV_CG_FIRST) {
+        // f, |g|, tolerances from the gradient launch's partials (rf_tron.h:154-169, 424-439)
+        double ar2 = 0, vv = 0, gg = 0, lq = 0;
+        for (int i = tid; i < np_in; i += 256) {
+            ar2 += Pbase[P_AR * (size_t)p.pstride + i]; vv += Pbase[P_VV * (size_t)p.pstride + i];
+            gg += Pbase[P_DOT * (size_t)p.pstride + i]; lq += Pbase[P_LQ * (size_t)p.pstride + i];
+        }
+        block_allsum3(ar2, vv, gg, smem);
+        lq = block_allsum(lq, smem);
+        const real ggr = (real)gg;                                           // BLAS dot in val_type
+        const double gnorm = sqrt((double)ggr);
+        const real cgtol = (real)(p.eps_cg * gnorm);                         // rf_tron.h:434
+        stopped = cg_stopped(ggr, cgtol);                                    // rho[0] = r^T r = g^T g (rf_tron.h:439)
+        if (blockIdx.x == 0 && tid == 0) {
+            // loss = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i): the reference's own formula on the full path
+            // (trmf.cpp:189-197); on the observed-entries path the same identity over the cached Grams
+            double f = 0.5 * (p.trYTY + lq);
+            if (p.lambdaI > 0) f += 0.5 * p.lambdaI * (double)(real)vv;      // trmf.cpp:73-75
+            if (p.nlag > 0 && p.lambdaAR > 0) f += 0.5 * p.lambdaAR * ar2;   // trmf.cpp:94
+            st->f = f; st->fnew = f; st->gnorm = gnorm; st->cgtol = cgtol; st->cg_rnorm = gnorm;
+            st->cg_iter = 0; st->accepted = 0; st->rho_hist[0] = (double)ggr;
+            st->cg_done = stopped ? 1 : 0; st->r_parity = 0;
         }
     }
-#endif
+    if (MODE == HV_CG_STEP) {
+        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
+        double dHd = 0, rHd = 0, HH = 0;
+        for (int i = tid; i < np_in; i += 256) {
+            dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i];
+        }
+        block_allsum3(dHd, rHd, HH, smem);
+        const double rho_prev_d = st->rho_hist[it - 1];
+        const real rho_prev = (real)rho_prev_d;
+        alpha = rho_prev / (real)dHd;                                        // rf_tron.h:460
+        nalpha = -alpha;
+        const double ad = (double)alpha;
+        const double rho_d = fmax(rho_prev_d - 2.0 * ad * rHd + ad * ad * HH, 0.0);   // |r - alpha Hd|^2
+        const real rho = (real)rho_d;
+        stopped = last || cg_stopped(rho, st->cgtol);                        // top of iteration `it`, rf_tron.h:444-446
+        const real beta = rho / rho_prev;                                    // rf_tron.h:495
+        tmp = beta - (real)1.0;                                              // rf_tron.h:497
+        if (blockIdx.x == 0 && tid == 0) {
+            st->rho_hist[it] = rho_d;
+            if (stopped) { st->cg_done = 1; st->r_parity = it & 1; }
+            else st->cg_iter = it + 1;                                       // nobody reads cg_iter during the solve
+        }
+    }
     if (nlag > 0) {
         auto put = [&](int e, real th) {
             const int tt = e / nlag, l = e - tt * nlag;
@@ -389,14 +451,26 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
     //     offset outside the vector reads 0 (its negative wraps to a huge unsigned), and the direction
     //     store goes through a descriptor that spans only the tile's own rows.
     const int sz = (int)sizeof(real);
-    const __amdgpu_buffer_rsrc_t v_rsrc = buffer_rsrc(v, (size_t)T * KP * sizeof(real));
-    const __amdgpu_buffer_rsrc_t r_rsrc = buffer_rsrc(FUSE_DIR ? rvec : v, (size_t)T * KP * sizeof(real));
+    const size_t vec_bytes = (size_t)T * KP * sizeof(real);
+    const __amdgpu_buffer_rsrc_t v_rsrc = buffer_rsrc(a.v, vec_bytes);
+    const __amdgpu_buffer_rsrc_t r_rsrc = buffer_rsrc(MODE == HV_CG_STEP ? a.r_in : a.v, vec_bytes);
+    const __amdgpu_buffer_rsrc_t h_rsrc = buffer_rsrc(MODE == HV_CG_STEP ? a.hd_in : a.v, vec_bytes);
+    // own-row descriptors: element eo of the tile's own rows; anything outside reads 0 / is dropped
+    const size_t own_bytes = (size_t)(i1 - i0) * KP * sizeof(real);
+    const __amdgpu_buffer_rsrc_t s_rsrc = buffer_rsrc(CG ? a.s + (size_t)i0 * KP : nullptr, CG ? own_bytes : 0);
+    const __amdgpu_buffer_rsrc_t do_rsrc = buffer_rsrc(CG ? a.d_out + (size_t)i0 * KP : nullptr, CG ? own_bytes : 0);
+    const __amdgpu_buffer_rsrc_t ro_rsrc = buffer_rsrc(CG ? a.r_out + (size_t)i0 * KP : nullptr, CG ? own_bytes : 0);
     const int vbyte0 = ((i0 - Hh) * KP + tid) * sz;          // wraps below zero for the first tiles: reads 0
-    real vr[kHvOperandRegs], rv[kHvOperandRegs];
+    const int obyte0 = (tid - Hh * KP) * sz;                 // the same element in own-row coordinates
+    real vr[kHvOperandRegs], rv[kHvOperandRegs], hr[kHvOperandRegs], sr[kHvOperandRegs];
 #pragma unroll
     for (int m = 0; m < kHvOperandRegs; m++) {
         vr[m] = buffer_load_real(v_rsrc, vbyte0 + 256 * m * sz);
-        if (FUSE_DIR) rv[m] = buffer_load_real(r_rsrc, vbyte0 + 256 * m * sz);
+        if (MODE == HV_CG_STEP) {
+            rv[m] = buffer_load_real(r_rsrc, vbyte0 + 256 * m * sz);
+            hr[m] = buffer_load_real(h_rsrc, vbyte0 + 256 * m * sz);
+            sr[m] = buffer_load_real(s_rsrc, obyte0 + 256 * m * sz);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
     // (b) the thread's slice of the cached Gram: columns [t0, t0+VEC) of timestamp row i0+lr, all KQ rows
@@ -418,24 +492,40 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
     }
     __builtin_amdgcn_sched_barrier(0);                      // keep the requests above everything that follows
 
-    // (1) operand rows -> LDS (zero outside [0,T)); FUSE_DIR: d_new = d + (beta-1) d + r
-    double ar2 = 0, vv = 0, dot = 0, lq = 0;
-    const __amdgpu_buffer_rsrc_t d_rsrc = buffer_rsrc(FUSE_DIR ? dnew + (size_t)i0 * KP : nullptr,
-                                                      FUSE_DIR ? (size_t)(i1 - i0) * KP * sizeof(real) : 0);
+    // (1) operand rows -> LDS (zeros outside [0,T) stay zeros through every update below)
+    double ar2 = 0, vv = 0, dot = 0, lq = 0, rhd = 0, hh = 0;
     const uint32_t own_n = (uint32_t)((i1 - i0) * KP);
-    auto operand = [&](int e, real x, real rx) {
-        if (FUSE_DIR) { x = fma(tmp, x, x); x = x + rx; }                  // zeros stay zero
+    auto operand = [&](int e, real x, real rx, real hx, real sx) {
         const int eo = e - Hh * KP;                                        // index within the tile's own rows
-        if (FUSE_DIR) buffer_store_real(d_rsrc, eo * sz, x);               // dropped outside them
-        if ((uint32_t)eo < own_n) vv += (double)x * (double)x;
+        if (CG) {
+            real rnew, snew;
+            if (MODE == HV_CG_FIRST) { x = -x; rnew = x; snew = 0; }       // s = 0, r = d = -g
+            else {
+                snew = fma(alpha, x, sx);                                  // s += alpha d      (rf_tron.h:461)
+                rnew = fma(nalpha, hx, rx);                                // r -= alpha Hd     (rf_tron.h:489-490)
+                x = fma(tmp, x, x); x = x + rnew;                          // d = beta d + r    (rf_tron.h:497-499)
+            }
+            buffer_store_real(s_rsrc, eo * sz, snew);                      // all three dropped outside the own rows
+            buffer_store_real(ro_rsrc, eo * sz, rnew);
+            buffer_store_real(do_rsrc, eo * sz, x);
+            if ((uint32_t)eo < own_n) rn[eo] = rnew;
+        } else {
+            if ((uint32_t)eo < own_n) vv += (double)x * (double)x;
+        }
         if (e < nV) vs[e] = x;
     };
 #pragma unroll
-    for (int m = 0; m < kHvOperandRegs; m++) operand(tid + 256 * m, vr[m], FUSE_DIR ? rv[m] : real(0));
+    for (int m = 0; m < kHvOperandRegs; m++)
+        operand(tid + 256 * m, vr[m], MODE == HV_CG_STEP ? rv[m] : real(0), MODE == HV_CG_STEP ? hr[m] : real(0),
+                MODE == HV_CG_STEP ? sr[m] : real(0));
 #pragma nounroll
-    for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256)             // very long halos only
-        operand(e, buffer_load_real(v_rsrc, vbyte0 + (e - tid) * sz),
-                FUSE_DIR ? buffer_load_real(r_rsrc, vbyte0 + (e - tid) * sz) : real(0));
+    for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256) {           // very long halos only
+        const int vb = vbyte0 + (e - tid) * sz, ob = obyte0 + (e - tid) * sz;
+        operand(e, buffer_load_real(v_rsrc, vb), MODE == HV_CG_STEP ? buffer_load_real(r_rsrc, vb) : real(0),
+                MODE == HV_CG_STEP ? buffer_load_real(h_rsrc, vb) : real(0),
+                MODE == HV_CG_STEP ? buffer_load_real(s_rsrc, ob) : real(0));
+    }
+    if (CG && stopped) return;                              // s and r are final; no further product
 #if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 2)
     const bool ar_on = false;
 #else
@@ -574,17 +664,29 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, const XState
 #pragma unroll
         for (int c = 0; c < VEC; c++) {
             if (live && t0 + c < k) {
-                double a = acc[c];
+                double ac = acc[c];
                 if (GRAD) {
-                    const double bb = (double)Bv[(size_t)i * KP + tcol[c]];
-                    lq += (double)x[c] * (a - 2.0 * bb);                     // w.(Gw) - 2 b.w
-                    a -= bb;
+                    const double bb = (double)a.Bv[(size_t)i * KP + tcol[c]];
+                    lq += (double)x[c] * (ac - 2.0 * bb);                    // w.(Gw) - 2 b.w
+                    ac -= bb;
                 }
-                const real oc = (real)(od[c] + a);
-                out[(size_t)i * KP + tpos[c]] = oc;
+                const real oc = (real)(od[c] + ac);
+                a.out[(size_t)i * KP + tpos[c]] = oc;
                 dot += (double)(GRAD ? oc : x[c]) * (double)oc;      // <g,g> for the gradient, <v,Hv> otherwise
+                if (CG) {
+                    rhd += (double)rn[rr * KP + tpos[c]] * (double)oc;       // <r,Hd>
+                    hh += (double)oc * (double)oc;                           // <Hd,Hd>
+                }
             }
         }
+    }
+    if (CG) {
+        block_allsum3(dot, rhd, hh, smem);
+        if (threadIdx.x == 0) {
+            double *Po = Pbase + (size_t)(P_CG0 + 3 * (it & 1)) * p.pstride;
+            Po[blockIdx.x] = dot; Po[(size_t)p.pstride + blockIdx.x] = rhd; Po[2 * (size_t)p.pstride + blockIdx.x] = hh;
+        }
+        return;
     }
     block_allsum3(ar2, vv, dot, smem);
     if (GRAD) {
@@ -625,6 +727,7 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
         st->cg_rnorm = gnorm;
         st->cg_iter = 0;
         st->accepted = 0;
+        st->cg_done = 0; st->r_parity = 0;
     }
     const size_t N = (size_t)p.T * p.KP;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
@@ -672,13 +775,16 @@ __global__ __launch_bounds__(256) void cg_update_kernel(XParams p, XState *__res
 }
 
 // ---- w_new = w + s ; partials <g,s>, <s,r>  (rf_tron.h:183-190) --------------------------------------
-__global__ __launch_bounds__(256) void wnew_kernel(XParams p, const real *__restrict__ w,
+__global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__restrict__ st,
+                                                   const real *__restrict__ w,
                                                    const real *__restrict__ s,
                                                    const real *__restrict__ g,
-                                                   const real *__restrict__ r,
+                                                   const real *__restrict__ r_even,
+                                                   const real *__restrict__ r_odd,
                                                    real *__restrict__ w_new,
                                                    double *__restrict__ Pbase) {
     __shared__ double smem[256];
+    const real *__restrict__ r = st->r_parity ? r_odd : r_even;   // fused CG: the launch that stopped wrote it
     const size_t N = (size_t)p.T * p.KP;
     double gs = 0, sr = 0;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
@@ -710,7 +816,8 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
     const double gs = (double)(real)sum_partials(Pbase + P_GS * (size_t)p.pstride, np, smem);
     const double sr = (double)(real)sum_partials(Pbase + P_SR * (size_t)p.pstride, np, smem);
     const double sHs = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
-    const double rho = (double)(real)sum_partials(Prr_final, np, smem);
+    const double rho = Prr_final ? (double)(real)sum_partials(Prr_final, np, smem)
+                                 : (double)(real)st->rho_hist[st->cg_iter];              // fused CG path
     const double f = st->f;
     const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190
     const double actred = -(gs + 0.5 * sHs);                                 // = f - f(w+s), exactly

@@ -76,7 +76,7 @@ struct TrmfSessionImpl {
     // device
     hipStream_t stream = nullptr;
     DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set;
-    DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, d0, d1, Hd, w_new;
+    DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, r1, d0, d1, Hd, Hd1, w_new;
     DevBuf<double> rAR, lossrow, partials, theta_part;
     // full-observation path (missing == 0)
     bool full = false, dense = false;
@@ -186,7 +186,7 @@ struct TrmfSessionImpl {
                 return kFail;
         }
         if (G.alloc((full ? 1 : (size_t)T * k * k) + kHvGramPad) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
-            d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
+            d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || r1.alloc(NV) || Hd1.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
             lossrow.alloc(T) || xstate.alloc(1) ||
             log.alloc(kLogCap))
             return kFail;
@@ -448,48 +448,41 @@ struct TrmfSessionImpl {
     }
 
     // ---- X-solve (trmf.cpp:665-674 -> rf_tron.h:134-254) -----------------------------------------------
-    // out = H*v (or the gradient when minus_b): fused LDS-tiled kernel when the AR halo fits, else the
-    // ar_residual + apply pair.  `fuse`: v is the previous direction and the new one is formed on the fly.
+    // Fused path (the AR halo fits LDS): hv_tile_kernel in its four roles, one launch per CG iteration.
+    template <int MODE> void launch_hv_tile(const HvVecs &a, int it, int last) {
+        const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
+#define TRMF_LAUNCH_HV_KQ(KQ)                                                                           \
+        hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ>), dim3(nbt), dim3(256), lds, stream, xp, xstate.p, a, nbt, it, last,  \
+                           lag_set.p, theta.p, Gmat(), partials.p, tile_TI)
+        switch (hv_kq(k) / 8) {
+            case 1: TRMF_LAUNCH_HV_KQ(8); break;
+            case 2: TRMF_LAUNCH_HV_KQ(16); break;
+            case 3: TRMF_LAUNCH_HV_KQ(24); break;
+            case 4: TRMF_LAUNCH_HV_KQ(32); break;
+            case 5: TRMF_LAUNCH_HV_KQ(40); break;
+            case 6: TRMF_LAUNCH_HV_KQ(48); break;
+            case 7: TRMF_LAUNCH_HV_KQ(56); break;
+            default: TRMF_LAUNCH_HV_KQ(64); break;
+        }
+#undef TRMF_LAUNCH_HV_KQ
+    }
+    // Unfused path (long lag sets): out = H*v (or the gradient when minus_b) as ar_residual + apply.
+    // `fuse`: v is the previous direction and the new one is formed on the fly.
     int hv(const real *v, bool fuse, const real *rvec, real *dnew, const double *Pcur, const double *Pprev,
            int minus_b, real *out, int dot_mode) {
         XState *st = xstate.p;
         double *Pb = partials.p;
-        if (tile_TI > 0) {
-            const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
-#define TRMF_LAUNCH_HV_KQ(FUSE, GRAD, KQ)                                                               \
-            hipLaunchKernelGGL((hv_tile_kernel<FUSE, GRAD, KQ>), dim3(nbt), dim3(256), lds, stream, xp, st, Pcur,   \
-                               Pprev, nbe, v, rvec, dnew, lag_set.p, theta.p, Gmat(), Bv.p, out, Pb, tile_TI)
-#define TRMF_LAUNCH_HV(FUSE, GRAD)                                                                      \
-            switch (hv_kq(k) / 8) {                                                                      \
-                case 1: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 8); break;                                         \
-                case 2: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 16); break;                                        \
-                case 3: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 24); break;                                        \
-                case 4: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 32); break;                                        \
-                case 5: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 40); break;                                        \
-                case 6: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 48); break;                                        \
-                case 7: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 56); break;                                        \
-                default: TRMF_LAUNCH_HV_KQ(FUSE, GRAD, 64); break;                                       \
-            }
-            if (fuse) { TRMF_LAUNCH_HV(true, false); }
-            else if (minus_b) { TRMF_LAUNCH_HV(false, true); }
-            else { TRMF_LAUNCH_HV(false, false); }
-#undef TRMF_LAUNCH_HV_KQ
-#undef TRMF_LAUNCH_HV
-        } else {
-            if (fuse)
-                hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
-                                   v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
-            else
-                hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
-                                   v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
-            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
-                               lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb);
-        }
+        if (fuse)
+            hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
+                               v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
+        else
+            hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
+                               v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
+        hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
+                           lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb);
         return 0;
     }
     const real *Gmat() const { return full ? GSx.p : G.p; }      // shared H^T H or the per-timestamp cache
-    int np_base() const { return tile_TI > 0 ? nbt : nbe; }   // blocks that wrote P_AR / P_VV
-    int np_dot() const { return tile_TI > 0 ? nbt : nba; }    // blocks that wrote P_DOT
 
     int xsolve() {
         XState *st = xstate.p;
@@ -499,10 +492,33 @@ struct TrmfSessionImpl {
         } else {
             if (gram_x()) return kFail;                                        // G, b
         }
-        hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0);           // gradient, <g,g>, AR/ridge sums
-        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, np_base(), np_dot(), g.p,
-                           s.p, r.p, d0.p);
         const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
+        if (tile_TI > 0 && maxcg <= kCgHistCap) {
+            real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
+            HvVecs a{};
+            a.v = W.p; a.out = g.p; a.Bv = Bv.p;
+            launch_hv_tile<HV_GRAD>(a, 0, 0);                                  // gradient, <g,g>, AR/ridge sums
+            a = HvVecs{};
+            a.v = g.p; a.s = s.p; a.d_out = dbuf[0]; a.r_out = rbuf[0]; a.out = hbuf[0];
+            launch_hv_tile<HV_CG_FIRST>(a, 0, 0);                              // f, |g|, cgtol; s = 0, r = d = -g; H d
+            for (int it = 1; it <= maxcg; it++) {                              // launch `maxcg` only closes the last iteration
+                a.v = dbuf[(it - 1) & 1]; a.r_in = rbuf[(it - 1) & 1]; a.hd_in = hbuf[(it - 1) & 1];
+                a.d_out = dbuf[it & 1]; a.r_out = rbuf[it & 1]; a.out = hbuf[it & 1];
+                launch_hv_tile<HV_CG_STEP>(a, it, it == maxcg ? 1 : 0);
+            }
+            hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1],
+                               w_new.p, Pb);
+            a = HvVecs{};
+            a.v = s.p; a.out = hbuf[0];
+            launch_hv_tile<HV_PLAIN>(a, 0, 0);                                 // H s, <s,Hs>
+            hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nbt,
+                               (const double *)nullptr, w_new.p, W.p);
+            TRMF_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
+        hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0);           // gradient, <g,g>, AR/ridge sums
+        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, g.p,
+                           s.p, r.p, d0.p);
         real *dcur = d0.p, *dalt = d1.p;
         for (int it = 0; it < maxcg; it++) {
             double *Pcur = P(P_RR0 + (it & 1)), *Pnext = P(P_RR0 + ((it + 1) & 1));
@@ -513,12 +529,12 @@ struct TrmfSessionImpl {
                 std::swap(dcur, dalt);
             }
             hipLaunchKernelGGL(cg_update_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pnext, P(P_DOT),
-                               nbe, np_dot(), it, dcur, Hd.p, s.p, r.p);
+                               nbe, nba, it, dcur, Hd.p, s.p, r.p);
         }
         double *Pfinal = P(P_RR0 + (maxcg & 1));
-        hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, W.p, s.p, g.p, r.p, w_new.p, Pb);
+        hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, r.p, r.p, w_new.p, Pb);
         hv(s.p, false, nullptr, nullptr, nullptr, nullptr, 0, Hd.p, 1);          // H s, <s,Hs>
-        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, np_dot(), Pfinal, w_new.p,
+        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, Pfinal, w_new.p,
                            W.p);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
