@@ -154,6 +154,36 @@ template <int SRC> __device__ __forceinline__ double quad_bcast(double v) {
 // e0 + (c&3)*estride + g; group u then takes its entry from quad lane u with a DPP quad_perm
 // broadcast) and FOUR vector loads of the gathered factor rows (column-interleaved layout: the NT
 // slices of a lane are contiguous).
+// The gathered factor rows are fetched through a buffer descriptor: address = descriptor base + ONE
+// 32-bit lane offset (row * row bytes + the lane's column bytes, two full-rate integer instructions),
+// instead of a 64-bit multiply-add per row (quarter rate, and the fp32 MFMA shares the vector ALUs
+// with every other VALU instruction -- scripts/ubench/mfma_valu.hip -- so each VALU cycle in this
+// loop is a cycle the Gram does not get).  Factor tables are therefore limited to 4 GiB.
+template <int NT>
+__device__ __forceinline__ RealVec<NT> load_factor_slice(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u3 __attribute__((ext_vector_type(3)));
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    constexpr int B = NT * (int)sizeof(real);
+    if constexpr (B == 4) return __builtin_bit_cast(RealVec<NT>, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0));
+    else if constexpr (B == 8) return __builtin_bit_cast(RealVec<NT>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0));
+    else if constexpr (B == 12) {
+        const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off, 0, 0);   // a 3-vector is padded to 16 bytes
+        RealVec<NT> r; __builtin_memcpy(&r, &t, B); return r;
+    }
+    else if constexpr (B == 16) return __builtin_bit_cast(RealVec<NT>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
+    else if constexpr (B == 24) {
+        struct { u4 lo; u2 hi; } t{__builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0),
+                                   __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off + 16, 0, 0)};
+        RealVec<NT> r; __builtin_memcpy(&r, &t, B); return r;
+    } else {
+        static_assert(B == 32, "slice size");
+        struct { u4 lo, hi; } t{__builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0),
+                                __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off + 16, 0, 0)};
+        return __builtin_bit_cast(RealVec<NT>, t);
+    }
+}
+
 template <int NT, int D, bool DO_MMA, bool WITH_LOSS, typename Next, typename RowDone>
 __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__restrict__ idx,
                                           const real *__restrict__ val, const real *__restrict__ X,
@@ -163,9 +193,11 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     static_assert(D == 4, "one quad lane per group of the iteration");
     constexpr int KP = kTile * NT;
     const uint32_t g = (uint32_t)(lane >> 4), c = (uint32_t)(lane & 15);
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<real *>(X), 0, -1 /* 4 GiB: no range check */, 0x00020000);
+    const uint32_t lane_bytes = (uint32_t)NT * c * (uint32_t)sizeof(real);
     uint32_t jraw; real yraw; bool vraw;                 // entries of iteration n+2 (as loaded)
     uint32_t jsel; real ysel;                            // entries of iteration n+1 (masked)
-    real x[D][NT], yx[D];
 
     auto load_entries = [&](const GramDesc &d) {
         const uint32_t p = d.e0 + (c & 3u) * estride + g;
@@ -178,22 +210,25 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
         jsel = vraw ? jraw : zero_row;
         ysel = vraw ? yraw : real(0);
     };
-    auto load_slices = [&](auto U) {                     // slot u <- factor row of group u of (jsel, ysel)
+    auto load_slices = [&](auto U, real (&x)[D][NT], real (&yx)[D]) {   // slot u <- factor row of group u
         constexpr int u = decltype(U)::value;
         const uint32_t j = quad_bcast<u>(jsel);
         yx[u] = quad_bcast<u>(ysel);
-        const RealVec<NT> v = *reinterpret_cast<const RealVec<NT> *>(X + (size_t)j * KP + NT * c);
+        const RealVec<NT> v = load_factor_slice<NT>(x_rsrc, (j * (uint32_t)NT) * (uint32_t)(kTile * sizeof(real)) + lane_bytes);
 #pragma unroll
         for (int q = 0; q < NT; q++) x[u][q] = v.v[q];
     };
 
     GramDesc d1 = d0; next(d1);
     GramDesc d2 = d1; next(d2);
+    real x[D][NT], yx[D];
     load_entries(d0);
     promote_entries();
-    static_for<D>([&](auto U) { load_slices(U); });
+    static_for<D>([&](auto U) { load_slices(U, x, yx); });
     load_entries(d1);
     real xc[D][NT], yc[D];                               // operands of the iteration being consumed
+    // (Two operand sets swapping roles would save the D*NT register copies below, but both stay live across
+    //  the caller's row_done -- the whole factorisation in the F-solve -- and spill there: measured slower.)
     while (d0.row >= 0) {
         // ---- single basic block ----
         // top: everything iteration n+1 / n+2 needs is requested first, so each load has a full
@@ -205,7 +240,7 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
             for (int q = 0; q < NT; q++) xc[u][q] = x[u][q];
         }
         promote_entries();                               // entries of n+1 (loaded one iteration ago)
-        static_for<D>([&](auto U) { load_slices(U); });  // slices of n+1 -> x / yx
+        static_for<D>([&](auto U) { load_slices(U, x, yx); });   // slices of n+1 -> x / yx
         load_entries(d2);                                // entries of n+2
         static_for<D>([&](auto U) {
             constexpr int u = decltype(U)::value;

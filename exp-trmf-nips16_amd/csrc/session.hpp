@@ -198,7 +198,8 @@ struct TrmfSessionImpl {
         rpb = std::max(1, 256 / k);
         nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
-            const int TI = hv_tile_rows(k);
+            int TI = hv_tile_rows(k);
+            if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
             if (hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
                 tile_TI = TI;
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup

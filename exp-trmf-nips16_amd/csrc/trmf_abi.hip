@@ -63,6 +63,11 @@ static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t l
     if (W->cols < 1 || W->cols > (uint64_t)kMaxRank) { fprintf(stderr, "[ERR MSG]: rank k=%ld outside the supported range 1..%d\n", (long)W->cols, kMaxRank); pass = false; }
     if (lag_size > (uint32_t)kMaxLags) { fprintf(stderr, "[ERR MSG]: |lag_set|=%u exceeds the supported %d\n", lag_size, kMaxLags); pass = false; }
     if (Y->nnz >= (1ull << 32) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
+    // gathered factor rows are addressed with 32-bit byte offsets (gram_ring): tables up to 4 GiB
+    const uint64_t rowbytes = (uint64_t)padded_rank((int)W->cols) * sizeof(real);
+    if ((Y->rows + 1) * rowbytes > 0xffffffffull || (Y->cols + 1) * rowbytes > 0xffffffffull) {
+        fprintf(stderr, "[ERR MSG]: factor tables exceed the 4 GiB of 32-bit gather offsets\n"); pass = false;
+    }
     return pass;
 }
 
