@@ -778,73 +778,60 @@ __global__ __launch_bounds__(128, 4) void fsolve_pc_kernel(const uint32_t *__res
 }
 #endif  // TRMF_F32
 
-// ---- X-side Gram cache: one workgroup (4 waves) per timestamp row ---------------------------------
+// ---- X-side Gram cache: one wavefront per timestamp row --------------------------------------------
+// G_i = sum_{j in Omega_i} h_j h_j^T (k x k, full symmetric, row-major) and b_i = sum_j y_ij h_j, straight
+// from the accumulator registers: diagonal tiles hold both triangles, an off-diagonal tile is written
+// twice (as is and mirrored).  No LDS, no workgroup barrier: a timestamp has ~nnz/T entries (1000 at
+// config 3), so one wavefront amortises the ring's two-iteration lead 60x instead of 15x, and the four
+// wavefronts of a workgroup never wait for each other.
 template <int NT>
 __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ idx,
                                                      const real *__restrict__ val,
                                                      const real *__restrict__ Hf,
-                                                     const real *__restrict__ W,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
                                                      uint32_t zero_row) {
-    constexpr int KP = kTile * NT, LD = KP + 1;
-    __shared__ real S[KP * LD];
-    __shared__ real Sb[KP];
+    constexpr int KP = kTile * NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    const uint32_t row = row_begin + blockIdx.x;
-    if (row >= row_end) return;
-    const uint32_t p0 = ptr[row], p1 = ptr[row + 1];
+    const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
+    if (row >= row_end) return;                         // wave-uniform; no block barrier below
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
 
     GramState<NT> st;
     st.clear();
-    real wq[NT];
+    real nowq[NT];
 #pragma unroll
-    for (int q = 0; q < NT; q++) wq[q] = W[(size_t)row * KP + NT * c + q];
-    {   // this wavefront takes groups wave, wave+4, ... of the row
-        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p0 + 4u * (uint32_t)wave));
-        const uint32_t e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)p1);
-        GramDesc d0{e0, e1, e0 < e1 ? 0 : -1};
-        // no per-entry residual here: the loss at w comes out of the gradient kernel as
-        // sum(y^2) + sum_i (w_i^T G_i w_i - 2 b_i.w_i)  (cg_init_kernel), ten VALU instructions per group cheaper
-        gram_ring<NT, kRingDepth, true, false>(st, idx, val, Hf, zero_row, 16u, lane, wq, d0,
-                                               SingleRowStream{16u * kRingDepth}, [](int) {});
-    }
+    for (int q = 0; q < NT; q++) nowq[q] = 0;
+    // no per-entry residual here: the loss at w comes out of the gradient kernel as
+    // sum(y^2) + sum_i (w_i^T G_i w_i - 2 b_i.w_i)  (HV_CG_FIRST / cg_init_kernel)
+    if (p1 > p0)
+        gram_ring<NT, kRingDepth, true, false>(st, idx, val, Hf, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
+                                               SingleRowStream{4u * kRingDepth}, [](int) {});
 #pragma unroll
-    for (int q = 0; q < NT; q++) {
-        st.b[q] += __shfl_xor(st.b[q], 16, kWave);
-        st.b[q] += __shfl_xor(st.b[q], 32, kWave);
-    }
-
-    for (int w = 0; w < 4; w++) {                       // ordered accumulation: deterministic
-        if (wave == w) {
-            int t = 0;
-#pragma unroll
-            for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-                for (int tj = ti; tj < NT; tj++, t++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int o = (kTile * ti + Mfma16<real>::row(lane, r)) * LD + kTile * tj + c;
-                        S[o] = (w == 0) ? st.acc[t][r] : S[o] + st.acc[t][r];
-                    }
-            if (g == 0) {
-#pragma unroll
-                for (int q = 0; q < NT; q++) {
-                    const int o = kTile * q + c;
-                    Sb[o] = (w == 0) ? st.b[q] : Sb[o] + st.b[q];
-                }
-            }
-        }
-        __syncthreads();
+    for (int q = 0; q < NT; q++) {                      // rhs: fold the 4 lane groups (logical column 16q + c)
+        real v = st.b[q];
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        if (g == 0) Bv[(size_t)row * KP + kTile * q + c] = (kTile * q + c < k) ? v : real(0);
     }
     real *Grow = G + (size_t)row * k * k;
-    for (int e = threadIdx.x; e < k * k; e += 256) {
-        const int s = e / k, t = e - s * k;
-        Grow[e] = (s <= t) ? S[s * LD + t] : S[t * LD + s];
-    }
-    if ((int)threadIdx.x < KP) Bv[(size_t)row * KP + threadIdx.x] = ((int)threadIdx.x < k) ? Sb[threadIdx.x] : real(0);
+    int t = 0;
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+        for (int tj = ti; tj < NT; tj++, t++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int rw = kTile * ti + Mfma16<real>::row(lane, r), cl = kTile * tj + c;
+                if (rw < k && cl < k) {
+                    const real a = st.acc[t][r];
+                    Grow[rw * k + cl] = a;
+                    if (ti != tj) Grow[cl * k + rw] = a;
+                }
+            }
 }
 
 // ---- loss only (f(w_new) of the TRON acceptance test, rf_tron.h:191) ------------------------------

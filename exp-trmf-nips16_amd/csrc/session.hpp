@@ -349,8 +349,8 @@ struct TrmfSessionImpl {
     // ---- X-side Gram cache / loss ---------------------------------------------------------------------
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
         if (re > rb)
-            hipLaunchKernelGGL((gram_x_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
-                               Yr_val.p, H.p, W.p, G.p, Bv.p, rb, re, k, (uint32_t)n);
+            hipLaunchKernelGGL((gram_x_kernel<NT_>), dim3((re - rb + 3) / 4), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
+                               Yr_val.p, H.p, G.p, Bv.p, rb, re, k, (uint32_t)n);
     }
     template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
         if (re > rb)
