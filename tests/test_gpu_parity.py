@@ -116,6 +116,25 @@ def test_fresh_seeded_problem_vs_restatement(dtype, k, nlag):
     assert abs(Jp - J64) / J64 < 3 * abs(Jo - J64) / J64 + tol['objective']
 
 
+@pytest.mark.parametrize('dtype,k,T', [(np.float64, 40, 27000), (np.float32, 12, 70000)])
+def test_long_series_many_hv_tiles(dtype, k, T):
+    """A long time axis: more than 1024 tiles of the fused CG kernel (one workgroup per tile, partial-sum
+    arrays sized at run time) and r/d/Hd ping-pong over many launches; 2 ALS iterations vs the
+    restatement (fp64 at the direct gate, fp32 at the SURVEY.md 8(d) gate)."""
+    nlag = 4
+    p = synth.sparse_problem(n=60, T=T, k=k, nlag=nlag, density=0.04, dtype=dtype, seed=11)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], k, seed=11)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    O.train_port(p['Y'], p['lag_set'], W, H, Th, synth.HYPER, max_iter=2, threads=8)
+    m = run_product(p['Y'], p['lag_set'], m0.W, m0.H, m0.lag_val, synth.HYPER, 2)
+    tol = TOL[np.dtype(dtype).name]
+    Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
+    Jp = O.objective(p['Y'], p['lag_set'], m.W, m.H, m.lag_val, synth.HYPER)
+    print('relfro W %.2e H %.2e Th %.2e dJ %.2e' % (relfro(m.W, W), relfro(m.H, H), relfro(m.lag_val, Th), abs(Jp - Jo) / Jo))
+    assert relfro(m.W, W) < tol['factor'] and relfro(m.H, H) < tol['factor']
+    assert abs(Jp - Jo) / Jo < tol['objective']
+
+
 def test_objective_parity_fp32_10_iterations_config2_shape():
     """north_star gate: fp32 objective within 1e-5 relative after 10 ALS iterations (config-2 shape)."""
     cfg = synth.CONFIGS['c2']
