@@ -159,28 +159,17 @@ template <int SRC> __device__ __forceinline__ double quad_bcast(double v) {
 // instead of a 64-bit multiply-add per row (quarter rate, and the fp32 MFMA shares the vector ALUs
 // with every other VALU instruction -- scripts/ubench/mfma_valu.hip -- so each VALU cycle in this
 // loop is a cycle the Gram does not get).  Factor tables are therefore limited to 4 GiB.
-template <int NT>
-__device__ __forceinline__ RealVec<NT> load_factor_slice(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
-    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
-    typedef unsigned int u3 __attribute__((ext_vector_type(3)));
-    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    constexpr int B = NT * (int)sizeof(real);
-    if constexpr (B == 4) return __builtin_bit_cast(RealVec<NT>, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0));
-    else if constexpr (B == 8) return __builtin_bit_cast(RealVec<NT>, __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0));
-    else if constexpr (B == 12) {
-        const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rsrc, byte_off, 0, 0);   // a 3-vector is padded to 16 bytes
-        RealVec<NT> r; __builtin_memcpy(&r, &t, B); return r;
-    }
-    else if constexpr (B == 16) return __builtin_bit_cast(RealVec<NT>, __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0));
-    else if constexpr (B == 24) {
-        struct { u4 lo; u2 hi; } t{__builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0),
-                                   __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off + 16, 0, 0)};
-        RealVec<NT> r; __builtin_memcpy(&r, &t, B); return r;
-    } else {
-        static_assert(B == 32, "slice size");
-        struct { u4 lo, hi; } t{__builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, 0, 0),
-                                __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off + 16, 0, 0)};
-        return __builtin_bit_cast(RealVec<NT>, t);
+// One load PER ELEMENT of the lane's slice (same descriptor, same lane offset, immediate offsets): a single
+// multi-dword load would force its destination into a register tuple, and the allocator then copies the
+// tuple's elements into the MFMA operand registers right after the load -- i.e. waits for it at once.
+template <int NT, typename R>
+__device__ __forceinline__ void load_factor_slice(R (&dst)[NT], __amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+        if constexpr (sizeof(R) == 4)
+            dst[q] = __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off + 4 * q, 0, 0));
+        else
+            dst[q] = __builtin_bit_cast(R, __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off + 8 * q, 0, 0));
     }
 }
 
@@ -214,9 +203,8 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
         constexpr int u = decltype(U)::value;
         const uint32_t j = quad_bcast<u>(jsel);
         yx[u] = quad_bcast<u>(ysel);
-        const RealVec<NT> v = load_factor_slice<NT>(x_rsrc, (j * (uint32_t)NT) * (uint32_t)(kTile * sizeof(real)) + lane_bytes);
-#pragma unroll
-        for (int q = 0; q < NT; q++) x[u][q] = v.v[q];
+        // row * row bytes + lane bytes as ONE full-rate v_mad_u32_u24 (rows < 2^24, checked at session creation)
+        load_factor_slice(x[u], x_rsrc, __umul24(j, (uint32_t)(KP * sizeof(real))) + lane_bytes);
     };
 
     GramDesc d1 = d0; next(d1);
@@ -226,41 +214,38 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     promote_entries();
     static_for<D>([&](auto U) { load_slices(U, x, yx); });
     load_entries(d1);
-    real xc[D][NT], yc[D];                               // operands of the iteration being consumed
-    // (Two operand sets swapping roles would save the D*NT register copies below, but both stay live across
-    //  the caller's row_done -- the whole factorisation in the F-solve -- and spill there: measured slower.)
+    // Slot u is consumed (its MFMAs and rhs FMAs issued) and then immediately re-requested for the next
+    // iteration, in place: every load still has a full iteration of MFMA time (24 x 32 cycles) to land, and
+    // there is no second operand set to copy into (12 + 4 register moves per iteration that the shared
+    // f32 ALUs would have to execute, section 4.1 (3) of DESIGN.md).
     while (d0.row >= 0) {
         // ---- single basic block ----
-        // top: everything iteration n+1 / n+2 needs is requested first, so each load has a full
-        // iteration of MFMA time (>= 24 x 32 cycles) to land before it is consumed
-#pragma unroll
-        for (int u = 0; u < D; u++) {
-            yc[u] = yx[u];
-#pragma unroll
-            for (int q = 0; q < NT; q++) xc[u][q] = x[u][q];
-        }
         promote_entries();                               // entries of n+1 (loaded one iteration ago)
-        static_for<D>([&](auto U) { load_slices(U, x, yx); });   // slices of n+1 -> x / yx
         load_entries(d2);                                // entries of n+2
         static_for<D>([&](auto U) {
             constexpr int u = decltype(U)::value;
 #pragma unroll
-            for (int q = 0; q < NT; q++) st.b[q] = fma(yc[u], xc[u][q], st.b[q]);
+            for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
             if (DO_MMA) {
                 int t = 0;
 #pragma unroll
                 for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(xc[u][ti], xc[u][tj], st.acc[t]);
+                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(x[u][ti], x[u][tj], st.acc[t]);
             }
             if (WITH_LOSS) {
                 real d = 0;
 #pragma unroll
-                for (int q = 0; q < NT; q++) d = fma(wq[q], xc[u][q], d);
+                for (int q = 0; q < NT; q++) d = fma(wq[q], x[u][q], d);
                 d = row16_sum(d);
-                const real res = yc[u] - d;               // trmf.cpp:238 (val_type arithmetic)
+                const real res = yx[u] - d;               // trmf.cpp:238 (val_type arithmetic)
                 st.loss += (double)res * (double)res;     // masked lanes: y = 0, x = 0 -> 0
             }
+            // pin the order "all of group u's arithmetic, then its reload": left alone, the scheduler moves the
+            // reload above MFMAs that still read the slot, renames it and waits for the fresh load at once
+            __builtin_amdgcn_sched_barrier(0);
+            load_slices(U, x, yx);                       // slot u <- group u of iteration n+1
+            __builtin_amdgcn_sched_barrier(0);
         });
         // ---- between iterations ----
         if (d1.row != d0.row) { row_done(d0.row); }

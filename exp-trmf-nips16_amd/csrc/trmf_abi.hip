@@ -65,8 +65,9 @@ static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t l
     if (Y->nnz >= (1ull << 32) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
     // gathered factor rows are addressed with 32-bit byte offsets (gram_ring): tables up to 4 GiB
     const uint64_t rowbytes = (uint64_t)padded_rank((int)W->cols) * sizeof(real);
-    if ((Y->rows + 1) * rowbytes > 0xffffffffull || (Y->cols + 1) * rowbytes > 0xffffffffull) {
-        fprintf(stderr, "[ERR MSG]: factor tables exceed the 4 GiB of 32-bit gather offsets\n"); pass = false;
+    if ((Y->rows + 1) * rowbytes > 0xffffffffull || (Y->cols + 1) * rowbytes > 0xffffffffull ||
+        Y->rows + 1 >= (1ull << 24) || Y->cols + 1 >= (1ull << 24)) {
+        fprintf(stderr, "[ERR MSG]: factor tables exceed the 4 GiB / 2^24 rows of 32-bit gather offsets\n"); pass = false;
     }
     return pass;
 }
