@@ -377,6 +377,21 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     }
     real tmp = 0, alpha = 0, nalpha = 0;
     bool stopped = false;
+    // HV_CG_STEP: the three dot-product partial arrays are requested FIRST (vmcnt retires in order), then the
+    // operand rows and the Gram slice, and only then reduced -- the whole request stream of the launch is
+    // in flight before the first wait.  (More than 512 tiles: read in a loop after the requests instead.)
+    constexpr int kEarlyPartials = 2;                       // x 256 threads
+    const bool early = MODE == HV_CG_STEP && np_in <= 256 * kEarlyPartials;
+    double pq[3][kEarlyPartials];
+    if (MODE == HV_CG_STEP && early) {
+        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
+#pragma unroll
+        for (int m = 0; m < kEarlyPartials; m++) {
+            const int i = min(tid + 256 * m, np_in - 1);
+#pragma unroll
+            for (int a3 = 0; a3 < 3; a3++) pq[a3][m] = Pp[(size_t)a3 * p.pstride + i];
+        }
+    }
     if (MODE == HV_CG_FIRST) {
         // f, |g|, tolerances from the gradient launch's partials (rf_tron.h:154-169, 424-439)
         double ar2 = 0, vv = 0, gg = 0, lq = 0;
@@ -399,29 +414,6 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             st->f = f; st->fnew = f; st->gnorm = gnorm; st->cgtol = cgtol; st->cg_rnorm = gnorm;
             st->cg_iter = 0; st->accepted = 0; st->rho_hist[0] = (double)ggr;
             st->cg_done = stopped ? 1 : 0; st->r_parity = 0;
-        }
-    }
-    if (MODE == HV_CG_STEP) {
-        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
-        double dHd = 0, rHd = 0, HH = 0;
-        for (int i = tid; i < np_in; i += 256) {
-            dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i];
-        }
-        block_allsum3(dHd, rHd, HH, smem);
-        const double rho_prev_d = st->rho_hist[it - 1];
-        const real rho_prev = (real)rho_prev_d;
-        alpha = rho_prev / (real)dHd;                                        // rf_tron.h:460
-        nalpha = -alpha;
-        const double ad = (double)alpha;
-        const double rho_d = fmax(rho_prev_d - 2.0 * ad * rHd + ad * ad * HH, 0.0);   // |r - alpha Hd|^2
-        const real rho = (real)rho_d;
-        stopped = last || cg_stopped(rho, st->cgtol);                        // top of iteration `it`, rf_tron.h:444-446
-        const real beta = rho / rho_prev;                                    // rf_tron.h:495
-        tmp = beta - (real)1.0;                                              // rf_tron.h:497
-        if (blockIdx.x == 0 && tid == 0) {
-            st->rho_hist[it] = rho_d;
-            if (stopped) { st->cg_done = 1; st->r_parity = it & 1; }
-            else st->cg_iter = it + 1;                                       // nobody reads cg_iter during the solve
         }
     }
     if (nlag > 0) {
@@ -491,6 +483,36 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         g_soff += (j + 1 < k) ? rowbytes : 0;               // j >= k: a finite duplicate, multiplied by a zero pad
     }
     __builtin_amdgcn_sched_barrier(0);                      // keep the requests above everything that follows
+
+    if (MODE == HV_CG_STEP) {
+        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
+        double dHd = 0, rHd = 0, HH = 0;
+        if (early) {
+#pragma unroll
+            for (int m = 0; m < kEarlyPartials; m++)
+                if (tid + 256 * m < np_in) { dHd += pq[0][m]; rHd += pq[1][m]; HH += pq[2][m]; }
+        } else {
+            for (int i = tid; i < np_in; i += 256) {
+                dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i];
+            }
+        }
+        block_allsum3(dHd, rHd, HH, smem);
+        const double rho_prev_d = st->rho_hist[it - 1];
+        const real rho_prev = (real)rho_prev_d;
+        alpha = rho_prev / (real)dHd;                                        // rf_tron.h:460
+        nalpha = -alpha;
+        const double ad = (double)alpha;
+        const double rho_d = fmax(rho_prev_d - 2.0 * ad * rHd + ad * ad * HH, 0.0);   // |r - alpha Hd|^2
+        const real rho = (real)rho_d;
+        stopped = last || cg_stopped(rho, st->cgtol);                        // top of iteration `it`, rf_tron.h:444-446
+        const real beta = rho / rho_prev;                                    // rf_tron.h:495
+        tmp = beta - (real)1.0;                                              // rf_tron.h:497
+        if (blockIdx.x == 0 && tid == 0) {
+            st->rho_hist[it] = rho_d;
+            if (stopped) { st->cg_done = 1; st->r_parity = it & 1; }
+            else st->cg_iter = it + 1;                                       // nobody reads cg_iter during the solve
+        }
+    }
 
     // (1) operand rows -> LDS (zeros outside [0,T) stay zeros through every update below)
     double ar2 = 0, vv = 0, dot = 0, lq = 0, rhd = 0, hh = 0;
