@@ -833,7 +833,8 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
                                                      const double *__restrict__ Pbase, int np,
                                                      int np_dot, const double *__restrict__ Prr_final,
                                                      const real *__restrict__ w_new,
-                                                     real *__restrict__ w) {
+                                                     real *__restrict__ w,
+                                                     XState *__restrict__ log_x, double *__restrict__ log_norms) {
     __shared__ double smem[256];
     const double gs = (double)(real)sum_partials(Pbase + P_GS * (size_t)p.pstride, np, smem);
     const double sr = (double)(real)sum_partials(Pbase + P_SR * (size_t)p.pstride, np, smem);
@@ -855,6 +856,12 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
         st->prered = prered; st->actred = actred;
         st->accepted = accept ? 1 : 0;
         st->cg_rnorm = sqrt(rho);
+        if (log_x) {                                    // iteration record written here: no copies on the stream
+            log_x->f = f; log_x->fnew = fnew; log_x->gnorm = st->gnorm; log_x->cg_rnorm = sqrt(rho);
+            log_x->actred = actred; log_x->prered = prered; log_x->gs = gs; log_x->sr = sr;
+            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0;
+            log_norms[0] = log_norms[1] = log_norms[2] = -1.0;      // ||.||^2 lines are off in this mode
+        }
     }
 }
 

@@ -485,7 +485,7 @@ struct TrmfSessionImpl {
     }
     const real *Gmat() const { return full ? GSx.p : G.p; }      // shared H^T H or the per-timestamp cache
 
-    int xsolve() {
+    int xsolve(XState *log_x = nullptr, double *log_n = nullptr) {   // log_*: record written by accept_kernel
         XState *st = xstate.p;
         double *Pb = partials.p;
         if (full) {
@@ -513,7 +513,7 @@ struct TrmfSessionImpl {
             a.v = s.p; a.out = hbuf[0];
             launch_hv_tile<HV_PLAIN>(a, 0, 0);                                 // H s, <s,Hs>
             hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nbt,
-                               (const double *)nullptr, w_new.p, W.p);
+                               (const double *)nullptr, w_new.p, W.p, log_x, log_n);
             TRMF_HIP_CHECK(hipGetLastError());
             return 0;
         }
@@ -536,7 +536,7 @@ struct TrmfSessionImpl {
         hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, r.p, r.p, w_new.p, Pb);
         hv(s.p, false, nullptr, nullptr, nullptr, nullptr, 0, Hd.p, 1);          // H s, <s,Hs>
         hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, Pfinal, w_new.p,
-                           W.p);
+                           W.p, log_x, log_n);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -578,11 +578,14 @@ struct TrmfSessionImpl {
             DeviceIterLog *L = log.p + ((iter1 - 1) % kLogCap);
             PhaseEvents &ev = events[(iter1 - 1) % kEventRing];
             static const DeviceIterLog blank = [] { DeviceIterLog b; std::memset(&b, 0, sizeof b); b.normF = b.normX = b.normLV = -1; return b; }();
-            TRMF_HIP_CHECK(hipMemcpyAsync(L, &blank, sizeof blank, hipMemcpyHostToDevice, stream));
-            TRMF_HIP_CHECK(hipEventRecord(ev.f0, stream));
             const bool doF = period_H > 0 && (iter1 % period_H) == 0;
             const bool doX = period_W > 0 && (iter1 % period_W) == 0;
             const bool doL = period_Lag > 0 && (iter1 % period_Lag) == 0;
+            // quiet runs: accept_kernel writes the whole record; otherwise a blank record is uploaded and the
+            // phases fill it in (two small copies per iteration on the stream)
+            const bool device_log = doX && !log_norms && !verbose;
+            if (!device_log) TRMF_HIP_CHECK(hipMemcpyAsync(L, &blank, sizeof blank, hipMemcpyHostToDevice, stream));
+            TRMF_HIP_CHECK(hipEventRecord(ev.f0, stream));
             if (doF) {
                 if (full ? fsolve_full(ev) : fsolve(ev)) return kFail;
                 if (log_norms || verbose) log_norm(H.p, (size_t)n * KP, &L->normF);
@@ -593,9 +596,10 @@ struct TrmfSessionImpl {
             }
             TRMF_HIP_CHECK(hipEventRecord(ev.f1, stream));
             if (doX) {
-                if (xsolve()) return kFail;
+                if (xsolve(device_log ? &L->x : nullptr, device_log ? &L->normF : nullptr)) return kFail;
                 if (log_norms || verbose) log_norm(W.p, (size_t)T * KP, &L->normX);
-                TRMF_HIP_CHECK(hipMemcpyAsync(&L->x, xstate.p, sizeof(XState), hipMemcpyDeviceToDevice, stream));
+                if (!device_log)
+                    TRMF_HIP_CHECK(hipMemcpyAsync(&L->x, xstate.p, sizeof(XState), hipMemcpyDeviceToDevice, stream));
                 if (verbose) {
                     fprintf(stderr, ">> iter %d X %g\n", iter1, host_double(&L->normX));
                     if (verbose >= 2) {
