@@ -61,7 +61,8 @@ __global__ __launch_bounds__(64) void theta_solve_kernel(const double *__restric
     const int t = blockIdx.x, lane = threadIdx.x;
     for (int p = lane; p < npairs; p += 64) {
         double acc = 0;
-        for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)t * nchunk + ch) * npairs + p];
+#pragma unroll 8
+        for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)t * nchunk + ch) * npairs + p];   // fixed order
         int a, b; bool rhs;
         theta_decode_pair(p, nlag, a, b, rhs);
         if (rhs) y[a] = (real)acc;
@@ -73,31 +74,38 @@ __global__ __launch_bounds__(64) void theta_solve_kernel(const double *__restric
         }
     }
     __syncthreads();
-    // upper Cholesky A = U^T U, row by row (posv 'U', rf_matrix.h:3008-3014)
+    // upper Cholesky A = U^T U, row by row (posv 'U', rf_matrix.h:3008-3014).  One wavefront: LDS accesses
+    // retire in program order, the barriers are wave-local.  The trailing update of step j runs over all
+    // (s, c) pairs at once (s > j, c >= s), 64 per pass -- same operations on every element, in the same j
+    // order, as the row-by-row loop.
     for (int j = 0; j < nlag; j++) {
         const real ajj = sqrt(A[j * nlag + j]);
         __syncthreads();
         for (int c = j + lane; c < nlag; c += 64) A[j * nlag + c] = (c == j) ? ajj : A[j * nlag + c] / ajj;
         __syncthreads();
-        for (int s = j + 1; s < nlag; s++) {
-            const real ujs = A[j * nlag + s];
-            for (int c = s + lane; c < nlag; c += 64) A[s * nlag + c] -= ujs * A[j * nlag + c];
+        const int m = nlag - 1 - j;                     // trailing dimension
+        for (int e = lane; e < m * m; e += 64) {
+            const int s = j + 1 + e / m, c = j + 1 + e % m;
+            if (c >= s) A[s * nlag + c] -= A[j * nlag + s] * A[j * nlag + c];
         }
         __syncthreads();
     }
-    if (lane == 0) {
-        for (int i = 0; i < nlag; i++) {                // U^T z = y
-            real s = y[i];
-            for (int q = 0; q < i; q++) s -= A[q * nlag + i] * y[q];
-            y[i] = s / A[i * nlag + i];
-        }
-        for (int i = nlag - 1; i >= 0; i--) {           // U x = z
-            real s = y[i];
-            for (int q = i + 1; q < nlag; q++) s -= A[i * nlag + q] * y[q];
-            y[i] = s / A[i * nlag + i];
-        }
+    // substitutions, column-oriented: after step q every remaining unknown has had its U(.,.)*z_q term removed:
+    // |L| steps of one parallel pass instead of |L|^2/2 dependent LDS round trips on a single lane.  Forward:
+    // the same subtractions in the same order as the row-oriented loop; backward: the terms of a row are
+    // subtracted in descending instead of ascending q (a last-bit difference in Theta)
+    for (int q = 0; q < nlag; q++) {                    // U^T z = y
+        if (lane == 0) y[q] = y[q] / A[q * nlag + q];
+        __syncthreads();
+        for (int i = q + 1 + lane; i < nlag; i += 64) y[i] -= A[q * nlag + i] * y[q];
+        __syncthreads();
     }
-    __syncthreads();
+    for (int q = nlag - 1; q >= 0; q--) {               // U x = z
+        if (lane == 0) y[q] = y[q] / A[q * nlag + q];
+        __syncthreads();
+        for (int i = lane; i < q; i += 64) y[i] -= A[i * nlag + q] * y[q];
+        __syncthreads();
+    }
     for (int a = lane; a < nlag; a += 64) theta[(size_t)t * nlag + a] = y[a];
 }
 
