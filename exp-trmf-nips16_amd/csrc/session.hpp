@@ -200,7 +200,9 @@ struct TrmfSessionImpl {
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
             int TI = hv_tile_rows(k);
             if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
-            if (hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
+            // the tile kernel addresses the CG vectors with 32-bit byte offsets through buffer descriptors
+            const bool fits32 = (uint64_t)(T + 1) * KP * sizeof(real) < 0x7fffffffull;
+            if (fits32 && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
                 tile_TI = TI;
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
