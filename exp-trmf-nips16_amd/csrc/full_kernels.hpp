@@ -73,38 +73,53 @@ __global__ __launch_bounds__(256) void dense_tn_kernel(const real *__restrict__ 
         for (int t = 0; t < KP; t++) dst[t] = acc[t];
     }
 }
-// out (M x KP, LOGICAL columns) = sum over chunks; positions of B's interleaved layout mapped back
+// out (M x KP, LOGICAL columns) = sum over chunks; positions of B's interleaved layout mapped back.
+// One wavefront per output element: lanes stride over the chunks, then a fixed-order butterfly -- the
+// chunk count goes up to ~1000 for tall-skinny products (few output rows, long contraction).
 __global__ __launch_bounds__(256) void dense_tn_reduce_kernel(const double *__restrict__ part, int nchunk,
                                                               int M, int KP, int NT, int k,
                                                               real *__restrict__ out) {
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t e = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (e >= (size_t)M * KP) return;
     const int m = (int)(e / KP), tp = (int)(e - (size_t)m * KP);
     double acc = 0;
-    for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)ch * M + m) * KP + tp];
+    for (int ch = lane; ch < nchunk; ch += 64) acc += part[((size_t)ch * M + m) * KP + tp];
+    acc = wave_butterfly_sum(acc);
     const int t = collog(tp, NT);
-    out[(size_t)m * KP + t] = (t < k) ? (real)acc : real(0);
+    if (lane == 0) out[(size_t)m * KP + t] = (t < k) ? (real)acc : real(0);
 }
 
 // ---- small Gram: GS (k x k, logical) = A^T A (+ lambda I) over the rows of a factor ------------------
-// grid = nblk workgroups, each over a contiguous row chunk; thread e owns entries e, e+256, ... of the
-// k x k result.  Partials are reduced in fixed order by small_gram_reduce_kernel.
+// grid = nblk workgroups, each over a contiguous row chunk staged kSgRows rows at a time in LDS; thread e
+// owns entries e, e+256, ... of the k x k result and adds the staged rows in order.  Partials are reduced
+// in fixed order by small_gram_reduce_kernel.
+constexpr int kSgRows = 32;
 __global__ __launch_bounds__(256) void small_gram_kernel(const real *__restrict__ A, int rows, int KP,
                                                          int NT, int k, double *__restrict__ part) {
-    __shared__ real srow[64];
+    __shared__ real srow[kSgRows][64];
     const int nblk = gridDim.x;
     const int r0 = (int)((long long)rows * blockIdx.x / nblk), r1 = (int)((long long)rows * (blockIdx.x + 1) / nblk);
     double acc[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) acc[u] = 0;
-    for (int r = r0; r < r1; r++) {
+    for (int rb = r0; rb < r1; rb += kSgRows) {
+        const int nr = min(kSgRows, r1 - rb);
         __syncthreads();
-        if ((int)threadIdx.x < k) srow[threadIdx.x] = A[(size_t)r * KP + colpos(threadIdx.x, NT)];
+        for (int x = threadIdx.x; x < nr * k; x += 256) {
+            const int rr = x / k, t = x - rr * k;
+            srow[rr][t] = A[(size_t)(rb + rr) * KP + colpos(t, NT)];
+        }
         __syncthreads();
 #pragma unroll
         for (int u = 0; u < 16; u++) {
             const int e = threadIdx.x + 256 * u;
-            if (e < k * k) acc[u] += (double)srow[e / k] * (double)srow[e % k];
+            if (e < k * k) {
+                const int s = e / k, t = e % k;
+                double a2 = acc[u];
+                for (int rr = 0; rr < nr; rr++) a2 += (double)srow[rr][s] * (double)srow[rr][t];
+                acc[u] = a2;
+            }
         }
     }
 #pragma unroll
@@ -113,15 +128,17 @@ __global__ __launch_bounds__(256) void small_gram_kernel(const real *__restrict_
         if (e < k * k) part[(size_t)blockIdx.x * k * k + e] = acc[u];
     }
 }
+// one wavefront per entry: lanes stride over the workgroup partials, fixed-order butterfly
 __global__ __launch_bounds__(256) void small_gram_reduce_kernel(const double *__restrict__ part, int nblk,
                                                                 int k, real lambda, real *__restrict__ GS) {
-    for (int e = threadIdx.x; e < k * k; e += 256) {
-        double acc = 0;
-        for (int b = 0; b < nblk; b++) acc += part[(size_t)b * k * k + e];
-        real v = (real)acc;
-        if (e / k == e % k) v += lambda;                                     // trmf.cpp:322-324
-        GS[e] = v;
-    }
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= k * k) return;
+    double acc = 0;
+    for (int b = lane; b < nblk; b += 64) acc += part[(size_t)b * k * k + e];
+    acc = wave_butterfly_sum(acc);
+    real v = (real)acc;
+    if (e / k == e % k) v += lambda;                                         // trmf.cpp:322-324
+    if (lane == 0) GS[e] = v;
 }
 
 // ---- shared-matrix solve: H[i][:] = GS^-1 b_i for every row (posv with n right-hand sides) -------------

@@ -392,12 +392,15 @@ struct TrmfSessionImpl {
                                out, rb, re, zero_row);
     }
     template <int NT_> void launch_dense_tn(const real *A, int K, int M, const real *B, real *out) {
-        hipLaunchKernelGGL((dense_tn_kernel<NT_>), dim3((M + 255) / 256, kGemmChunks), dim3(256), 0, stream, A, K, M, B,
-                           gemm_part.p);
-        hipLaunchKernelGGL(dense_tn_reduce_kernel, dim3((unsigned)(((size_t)M * KP + 255) / 256)), dim3(256), 0, stream,
-                           gemm_part.p, kGemmChunks, M, KP, NT, k, out);
+        // contraction chunks: enough workgroups to fill the chip even when there are only a few hundred output
+        // rows (Y^T W of a tall series matrix), within the partial buffer (kGemmChunks * max(n,T) rows)
+        const int xb = (M + 255) / 256;
+        const long long cap = (long long)kGemmChunks * std::max(n, T) / std::max(M, 1);
+        const int nchunk = (int)std::max<long long>(1, std::min<long long>({cap, (long long)K, std::max<long long>(kGemmChunks, 2048 / xb)}));
+        hipLaunchKernelGGL((dense_tn_kernel<NT_>), dim3(xb, nchunk), dim3(256), 0, stream, A, K, M, B, gemm_part.p);
+        hipLaunchKernelGGL(dense_tn_reduce_kernel, dim3((unsigned)(((size_t)M * KP + 3) / 4)), dim3(256), 0, stream,
+                           gemm_part.p, nchunk, M, KP, NT, k, out);
     }
-    // out (rows x KP, logical columns) = op(Y) * X, rows [rb, re) (dense: all rows)
     int y_times_factor(bool transposed, const real *X, real *out, uint32_t rb, uint32_t re) {
         if (!dense) {
             const uint32_t *ptr = transposed ? Yc_ptr.p : Yr_ptr.p, *idx = transposed ? Yc_idx.p : Yr_idx.p;
@@ -425,7 +428,7 @@ struct TrmfSessionImpl {
     int small_gram(const real *A, int rows, real lambda, real *GS) {
         const int nb = std::min(kSmallGramBlocks, std::max(1, rows));
         hipLaunchKernelGGL(small_gram_kernel, dim3(nb), dim3(256), 0, stream, A, rows, KP, NT, k, sgram_part.p);
-        hipLaunchKernelGGL(small_gram_reduce_kernel, dim3(1), dim3(256), 0, stream, sgram_part.p, nb, k, lambda, GS);
+        hipLaunchKernelGGL(small_gram_reduce_kernel, dim3((k * k + 3) / 4), dim3(256), 0, stream, sgram_part.p, nb, k, lambda, GS);
         return 0;
     }
     int fsolve_full(PhaseEvents &ev) {
