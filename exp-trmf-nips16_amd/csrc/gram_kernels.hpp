@@ -416,22 +416,12 @@ __device__ __forceinline__ void quad_factor_solve(float (&areg)[NT][KMAX], float
 #pragma unroll
             for (int q = qj; q < NT; q++) bz[q] = fmaf(-u[q], zj, bz[q]);
             if (c == cj) { bz[qj] = zj; dinv[qj] = inv; }
-            // trailing update, two rows per instruction: (A[s][.], A[s+1][.]) -= (u_s, u_{s+1}) * u[.] is one
-            // packed-f32 FMA (v_pk_fma_f32: twice the FMAs per issue slot of the shared f32 ALUs)
-            static_for<KMAX / 2>([&](auto Px) {
-                constexpr int s0 = 2 * decltype(Px)::value, qs = s0 >> 4;
-                if constexpr (s0 + 1 > j) {
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    f2 m;
-                    m.x = (s0 > j) ? row_bcast<(s0 & 15)>(u[qs]) : 0.0f;     // row j itself stays (multiplier 0)
-                    m.y = row_bcast<((s0 + 1) & 15)>(u[qs]);
+            static_for<KMAX>([&](auto Sx) {
+                constexpr int s = decltype(Sx)::value, qs = s >> 4, cs = s & 15;
+                if constexpr (s > j) {
+                    const float us = row_bcast<cs>(u[qs]);
 #pragma unroll
-                    for (int q = qs; q < NT; q++) {
-                        f2 a = {areg[q][s0], areg[q][s0 + 1]};
-                        const f2 uu = {u[q], u[q]};
-                        a = __builtin_elementwise_fma(-m, uu, a);
-                        areg[q][s0] = a.x; areg[q][s0 + 1] = a.y;
-                    }
+                    for (int q = qs; q < NT; q++) areg[q][s] = fmaf(-us, u[q], areg[q][s]);
                 }
             });
         }
