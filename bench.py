@@ -212,7 +212,7 @@ def main():
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
                 args.config, cfg['n'], cfg['T'], cfg.get('density', 1.0), nnz, cfg['k'], len(prob['lag_set']), dtype.name,
                 int(missing), hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
-                'parallelism': 'F rows / X-Gram rows sharded x{}, CG replicated'.format(world)},
+                'parallelism': 'F rows / X-Gram rows sharded x{}, X-Gram build replicated instead when its all-gather costs more than it saves (decided once, after the first measured iteration), CG replicated'.format(world)},
             'roofline': {'kernel': 'fsolve_quad_kernel<3,40>' if dtype == np.float32 else 'fsolve_kernel', 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,

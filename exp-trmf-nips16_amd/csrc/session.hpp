@@ -99,6 +99,7 @@ struct TrmfSessionImpl {
             hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.x1, e.lv1};
             for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
         }
+        for (hipEvent_t ev : {gx0, gx1, gx2}) if (ev) (void)hipEventDestroy(ev);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -229,6 +230,10 @@ struct TrmfSessionImpl {
             hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
             for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
+        for (hipEvent_t *ev : {&gx0, &gx1, &gx2}) TRMF_HIP_CHECK(hipEventCreate(ev));
+        if (gramx_times.alloc((size_t)2 * comm->world)) return kFail;
+        if (comm->world == 1) gramx_mode = kGramxShard;              // nothing to decide
+        if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
         TRMF_HIP_CHECK(hipDeviceSynchronize());
         return 0;
     }
@@ -303,6 +308,14 @@ struct TrmfSessionImpl {
     bool use_quad = sizeof(real) == 4;
     bool use_pc = false;
     DevBuf<int> dev_err;
+    // X-side Gram build across ranks: sharded rows + all-gather of G (64 MB at config 3) pays only when a
+    // rank's share of the gather is cheaper than the rows it no longer computes -- true on 8 GPUs, not on 2.
+    // First call measures (kernel and gather time of every rank, exchanged through the communicator so that
+    // all ranks take the same decision); TRMF_GRAMX=shard|replicate overrides.
+    enum { kGramxMeasure = 0, kGramxShard = 1, kGramxReplicate = 2 };
+    int gramx_mode = kGramxMeasure, gramx_calls = 0;
+    hipEvent_t gx0 = nullptr, gx1 = nullptr, gx2 = nullptr;
+    DevBuf<double> gramx_times;
     int dbg_flags = 0;           // TRMF_DEBUG_ABLATE: bit0 skip Gram, bit1 skip factorisation, bit2 skip back-solve
     int fsolve(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
@@ -360,7 +373,12 @@ struct TrmfSessionImpl {
                                Yr_val.p, H.p, Wv, lossrow.p, rb, re, (uint32_t)n);
     }
     int gram_x() {
-        const uint32_t rb = (uint32_t)xbounds[comm->rank], re = (uint32_t)xbounds[comm->rank + 1];
+        if (gramx_mode == kGramxMeasure && gramx_calls == 1 && gramx_decide()) return kFail;
+        const bool replicate = gramx_mode == kGramxReplicate;
+        const bool measure = gramx_mode == kGramxMeasure;
+        const uint32_t rb = replicate ? 0u : (uint32_t)xbounds[comm->rank];
+        const uint32_t re = replicate ? (uint32_t)T : (uint32_t)xbounds[comm->rank + 1];
+        if (measure) TRMF_HIP_CHECK(hipEventRecord(gx0, stream));
         switch (NT) {
             case 1: launch_gram_x<1>(rb, re); break;
             case 2: launch_gram_x<2>(rb, re); break;
@@ -368,8 +386,39 @@ struct TrmfSessionImpl {
             default: launch_gram_x<4>(rb, re); break;
         }
         TRMF_HIP_CHECK(hipGetLastError());
+        gramx_calls++;
+        if (replicate) return 0;                                    // every rank built every row: nothing to gather
+        if (measure) TRMF_HIP_CHECK(hipEventRecord(gx1, stream));
         if (gather_rows(G.p, xbounds, (size_t)k * k * sizeof(real))) return kFail;
-        return gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real));
+        if (gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
+        if (measure) TRMF_HIP_CHECK(hipEventRecord(gx2, stream));
+        return 0;
+    }
+    // One-time decision after the first (measured, sharded) build.  Rank r publishes (kernel ms, gather ms);
+    // after the exchange every rank evaluates the same rule on the same numbers.
+    int gramx_decide() {
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        float tk = 0, tg = 0;
+        TRMF_HIP_CHECK(hipEventElapsedTime(&tk, gx0, gx1));
+        TRMF_HIP_CHECK(hipEventElapsedTime(&tg, gx1, gx2));
+        const double mine[2] = {(double)tk, (double)tg};
+        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 2 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
+        std::vector<uint64_t> off(comm->world + 1);
+        for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * sizeof mine;
+        if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<double> all((size_t)2 * comm->world);
+        TRMF_HIP_CHECK(hipMemcpy(all.data(), gramx_times.p, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double t_all_rows = 0, t_sharded = 0;
+        for (int r = 0; r < comm->world; r++) {
+            t_all_rows += all[2 * r];                                        // one GPU doing every rank's rows
+            t_sharded = std::max(t_sharded, all[2 * r] + all[2 * r + 1]);    // slowest rank: its rows + the gather
+        }
+        gramx_mode = (t_all_rows < 0.95 * t_sharded) ? kGramxReplicate : kGramxShard;
+        if (verbose && comm->rank == 0)
+            fprintf(stderr, ">> X-side Gram build: all rows %.3f ms vs sharded %.3f ms -> %s\n", t_all_rows, t_sharded,
+                    gramx_mode == kGramxReplicate ? "replicated" : "sharded");
+        return 0;
     }
     int loss(const real *Wv, bool all_rows) {
         const uint32_t rb = all_rows ? 0u : (uint32_t)xbounds[comm->rank];
