@@ -268,6 +268,10 @@ __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, in
 constexpr int kHvThetaRegs = 3;                  // Theta elements per thread loaded ahead of the scalar prologue
 constexpr int kHvResU = 2;                       // AR residual work items (4 columns each) a thread carries through the lag loop
 constexpr int kHvOperandRegs = 12;               // operand elements per thread requested ahead of the Gram
+#ifndef TRMF_HV_UPFRONT
+#define TRMF_HV_UPFRONT 96
+#endif
+constexpr int kHvGramUpfront = TRMF_HV_UPFRONT;  // registers of the Gram slice requested before the LDS phases
 constexpr int kHvGramPad = 4;                    // elements allocated past the Gram cache (vector tail reads)
 // Gram columns per thread: one 16-byte load per Gram row up to rank 40, 8-byte loads above (the thread's
 // slice, KQ loads, has to stay within ~160 of the 256 registers)
@@ -470,8 +474,10 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     const int lr = tid / tpr, t0 = (tid - lr * tpr) * VEC;
     const bool lane_on = lr < TI;
     const int lrc = lane_on ? lr : TI - 1;                  // idle lanes shadow a live one (no branches)
-    // The first KA Gram rows (<= 128 registers) are requested here; the rest after phase 2 (a full 160-register slice next to them does not fit 256).
-    constexpr int KA = (KQ * VEC * (int)sizeof(real) / 4 <= 128) ? KQ : 128 / (VEC * (int)sizeof(real) / 4);
+    // The first KA Gram rows (kHvGramUpfront = 96 registers) are requested here, the rest after phase 2: the AR phases
+    // need registers for their independent LDS reads (measured: 96 up front beats 128, 144 and 160; 32..96 are equal --
+    // the stream is bandwidth-bound once it has started, it only must not start late).
+    constexpr int KA = (KQ * VEC * (int)sizeof(real) / 4 <= kHvGramUpfront) ? KQ : kHvGramUpfront / (VEC * (int)sizeof(real) / 4);
     GramVec<VEC> gq[KQ];
     const __amdgpu_buffer_rsrc_t g_rsrc = buffer_rsrc(G + (size_t)i0 * p.gstride, 0x7fffffff);
     const int g_voff = (int)(((uint32_t)(min(i0 + lrc, T - 1) - i0) * (uint32_t)p.gstride + (uint32_t)t0) * sizeof(real));
