@@ -266,7 +266,10 @@ __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, in
     return a + b + c + (size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)nlag * sizeof(int);  // + lambdaAR*Theta, Theta, lag_set
 }
 constexpr int kHvThetaRegs = 3;                  // Theta elements per thread loaded ahead of the scalar prologue
-constexpr int kHvResU = 2;                       // AR residual work items (4 columns each) a thread carries through the lag loop
+#ifndef TRMF_HV_RESU
+#define TRMF_HV_RESU 2
+#endif
+constexpr int kHvResU = TRMF_HV_RESU;                       // AR residual work items (4 columns each) a thread carries through the lag loop
 constexpr int kHvOperandRegs = 12;               // operand elements per thread requested ahead of the Gram
 #ifndef TRMF_HV_UPFRONT
 #define TRMF_HV_UPFRONT 96
