@@ -147,6 +147,21 @@ template <int SRC> __device__ __forceinline__ double quad_bcast(double v) {
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// RHS_PAD: y rides in the pad columns of the MFMA panel.  quad_inject<SRC>(x, y): lanes 12..15 of every
+// 16-lane row (slice NT-1 there = logical columns 16(NT-1)+12 .. +15, pads when k <= 16 NT - 4) take y of
+// lane (quad base + SRC), all other lanes keep x -- one DPP move with a bank mask, the same instruction
+// that used to broadcast y for the rhs FMAs.  The Gram's columns KP-4..KP-1 then hold b = sum y x.
+template <int SRC> __device__ __forceinline__ float quad_inject(float x, float y) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(y), 0x55 * SRC, 0xf, 0x8, false));
+}
+template <int SRC> __device__ __forceinline__ double quad_inject(double x, double y) {
+    const long long xb = __double_as_longlong(x), yb = __double_as_longlong(y);
+    const int lo = __builtin_amdgcn_update_dpp((int)(xb & 0xffffffffLL), (int)(yb & 0xffffffffLL), 0x55 * SRC, 0xf, 0x8, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(xb >> 32), (int)(yb >> 32), 0x55 * SRC, 0xf, 0x8, false);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int NT> __host__ __device__ constexpr bool rhs_pad_ok(int k) { return k <= kTile * NT - 8; }
+
 // next(desc): advance a wave-uniform descriptor to the following iteration of the stream.
 // row_done(row): called between iterations when the stream leaves `row` (st holds its Gram/rhs/loss).
 //
@@ -173,7 +188,7 @@ __device__ __forceinline__ void load_factor_slice(R (&dst)[NT], __amdgpu_buffer_
     }
 }
 
-template <int NT, int D, bool DO_MMA, bool WITH_LOSS, typename Next, typename RowDone>
+template <int NT, int D, bool DO_MMA, bool WITH_LOSS, bool RHS_PAD = false, typename Next, typename RowDone>
 __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__restrict__ idx,
                                           const real *__restrict__ val, const real *__restrict__ X,
                                           uint32_t zero_row, uint32_t estride, int lane,
@@ -202,7 +217,7 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     auto load_slices = [&](auto U, real (&x)[D][NT], real (&yx)[D]) {   // slot u <- factor row of group u
         constexpr int u = decltype(U)::value;
         const uint32_t j = quad_bcast<u>(jsel);
-        yx[u] = quad_bcast<u>(ysel);
+        if constexpr (!RHS_PAD) yx[u] = quad_bcast<u>(ysel);
         // row * row bytes + lane bytes as ONE full-rate v_mad_u32_u24 (rows < 2^24, checked at session creation)
         load_factor_slice(x[u], x_rsrc, __umul24(j, (uint32_t)(KP * sizeof(real))) + lane_bytes);
     };
@@ -220,18 +235,25 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     // f32 ALUs would have to execute, section 4.1 (3) of DESIGN.md).
     while (d0.row >= 0) {
         // ---- single basic block ----
+        const real ycons = ysel;                         // y of the iteration being consumed (RHS_PAD)
         promote_entries();                               // entries of n+1 (loaded one iteration ago)
         load_entries(d2);                                // entries of n+2
         static_for<D>([&](auto U) {
             constexpr int u = decltype(U)::value;
+            real xt[NT];                                 // operands of group u; the last slice carries y in its pads
 #pragma unroll
-            for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
+            for (int q = 0; q < NT; q++) xt[q] = x[u][q];
+            if constexpr (RHS_PAD) xt[NT - 1] = quad_inject<u>(x[u][NT - 1], ycons);
+            else {
+#pragma unroll
+                for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
+            }
             if (DO_MMA) {
                 int t = 0;
 #pragma unroll
                 for (int ti = 0; ti < NT; ti++)
 #pragma unroll
-                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(x[u][ti], x[u][tj], st.acc[t]);
+                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(xt[ti], xt[tj], st.acc[t]);
             }
             if (WITH_LOSS) {
                 real d = 0;
@@ -515,11 +537,16 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
     st.clear();
     // system `sys` is complete in st: + lambda on the diagonal (trmf.cpp:393), accumulators -> slab
     // (4 consecutive rows per store), then lane row `sys` pulls its columns into registers
+    // rhs in the pad columns of the panel (quad_inject) when the rank leaves >= 8 pad columns: b_s = A[s][KP-1]
+    constexpr bool PAD = KMAX <= kTile * NT - 8;
+    constexpr int kBcol = quad_slab_col_offset<NT>(NT - 1) + 15 * (kTile * NT + 4);      // slab column KP-1
     auto finalize = [&](int sys) {
+        if constexpr (!PAD) {
 #pragma unroll
-        for (int q = 0; q < NT; q++) {
-            st.b[q] += __shfl_xor(st.b[q], 16, kWave);
-            st.b[q] += __shfl_xor(st.b[q], 32, kWave);
+            for (int q = 0; q < NT; q++) {
+                st.b[q] += __shfl_xor(st.b[q], 16, kWave);
+                st.b[q] += __shfl_xor(st.b[q], 32, kWave);
+            }
         }
         int t = 0;
 #pragma unroll
@@ -540,7 +567,7 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
             mine = true;
 #pragma unroll
             for (int q = 0; q < NT; q++) {
-                bz[q] = st.b[q];
+                bz[q] = PAD ? S[kBcol + kTile * q + c] : st.b[q];
 #pragma unroll
                 for (int s4 = 0; s4 < KMAX / 4; s4++) {
                     if (4 * s4 <= kTile * q + 15) {
@@ -560,8 +587,8 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
         float nowq[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) nowq[q] = 0;
-        gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, stream.first(), stream,
-                                               finalize);
+        gram_ring<NT, kRingDepth, true, false, PAD>(st, idx, val, X, zero_row, 4u, lane, nowq, stream.first(), stream,
+                                                    finalize);
     }
 
     float x[NT];
@@ -769,7 +796,7 @@ __global__ __launch_bounds__(128, 4) void fsolve_pc_kernel(const uint32_t *__res
 // twice (as is and mirrored).  No LDS, no workgroup barrier: a timestamp has ~nnz/T entries (1000 at
 // config 3), so one wavefront amortises the ring's two-iteration lead 60x instead of 15x, and the four
 // wavefronts of a workgroup never wait for each other.
-template <int NT>
+template <int NT, bool RHS_PAD>
 __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ idx,
                                                      const real *__restrict__ val,
@@ -793,14 +820,28 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
     // no per-entry residual here: the loss at w comes out of the gradient kernel as
     // sum(y^2) + sum_i (w_i^T G_i w_i - 2 b_i.w_i)  (HV_CG_FIRST / cg_init_kernel)
     if (p1 > p0)
-        gram_ring<NT, kRingDepth, true, false>(st, idx, val, Hf, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
-                                               SingleRowStream{4u * kRingDepth}, [](int) {});
+        gram_ring<NT, kRingDepth, true, false, RHS_PAD>(st, idx, val, Hf, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
+                                                        SingleRowStream{4u * kRingDepth}, [](int) {});
+    if constexpr (RHS_PAD) {                            // rhs = column KP-1 of the panel Gram: tiles (ti, NT-1), lane column 15
+        if (c == 15) {
 #pragma unroll
-    for (int q = 0; q < NT; q++) {                      // rhs: fold the 4 lane groups (logical column 16q + c)
-        real v = st.b[q];
-        v += __shfl_xor(v, 16, kWave);
-        v += __shfl_xor(v, 32, kWave);
-        if (g == 0) Bv[(size_t)row * KP + kTile * q + c] = (kTile * q + c < k) ? v : real(0);
+            for (int ti = 0; ti < NT; ti++) {
+                const int t = ti * NT - ti * (ti - 1) / 2 + (NT - 1 - ti);         // index of tile (ti, NT-1)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int tt = kTile * ti + Mfma16<real>::row(lane, r);
+                    Bv[(size_t)row * KP + tt] = (tt < k) ? st.acc[t][r] : real(0);
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NT; q++) {                  // rhs: fold the 4 lane groups (logical column 16q + c)
+            real v = st.b[q];
+            v += __shfl_xor(v, 16, kWave);
+            v += __shfl_xor(v, 32, kWave);
+            if (g == 0) Bv[(size_t)row * KP + kTile * q + c] = (kTile * q + c < k) ? v : real(0);
+        }
     }
     real *Grow = G + (size_t)row * k * k;
     int t = 0;

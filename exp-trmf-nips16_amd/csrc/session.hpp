@@ -363,9 +363,14 @@ struct TrmfSessionImpl {
 
     // ---- X-side Gram cache / loss ---------------------------------------------------------------------
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
-        if (re > rb)
-            hipLaunchKernelGGL((gram_x_kernel<NT_>), dim3((re - rb + 3) / 4), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
-                               Yr_val.p, H.p, G.p, Bv.p, rb, re, k, (uint32_t)n);
+        if (re <= rb) return;
+        const dim3 grid((re - rb + 3) / 4), block(256);
+        if (rhs_pad_ok<NT_>(k))       // rhs accumulated by the MFMAs in the panel's pad columns
+            hipLaunchKernelGGL((gram_x_kernel<NT_, true>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p,
+                               Bv.p, rb, re, k, (uint32_t)n);
+        else
+            hipLaunchKernelGGL((gram_x_kernel<NT_, false>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p,
+                               Bv.p, rb, re, k, (uint32_t)n);
     }
     template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
         if (re > rb)
