@@ -85,7 +85,7 @@ def test_session_log_matches_reference_observables(name):
 
 @pytest.mark.parametrize('dtype,k,nlag', [(np.float32, 16, 8), (np.float32, 40, 16), (np.float64, 24, 4),
                                           (np.float64, 60, 5), (np.float32, 3, 2), (np.float32, 64, 32),
-                                          (np.float32, 24, 6), (np.float32, 56, 12), (np.float64, 36, 3)])
+                                          (np.float32, 24, 6), (np.float32, 56, 12), (np.float64, 36, 3), (np.float64, 64, 32)])
 def test_fresh_seeded_problem_vs_restatement(dtype, k, nlag):
     """4 ALS iterations vs the restatement.  Gate: SURVEY.md 8(d) tolerances.  A truncated fp32 CG on
     an ill-conditioned system amplifies last-bit differences (the reference's own fp32 build has the
