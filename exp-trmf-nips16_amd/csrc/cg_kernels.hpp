@@ -8,7 +8,11 @@
 //   * the host enqueues the whole solve without a single synchronisation,
 //   * every workgroup -- and, with several GPUs, every rank -- derives bit-identical scalars,
 //   * a stop is "sticky": once ||r|| <= cgtol, cg_update_kernel only forwards the partials, so all
-//     later (already enqueued) iterations see the same r^T r and do nothing.
+//     later (already enqueued) iterations see the same r^T r and do nothing.  The fused path records
+//     the ITERATION INDEX of the stopping launch (XState::stop_it); launch `it` returns early only
+//     when stop_it < it, a value that can only have been written by an EARLIER launch -- the
+//     stopping launch itself always sees "not stopped yet" in every one of its workgroups, whatever
+//     order they are dispatched in, and closes s and r for all of its rows.
 //
 // Vectors are T x KP row-major (KP = padded rank); pad columns are zero and stay zero.
 #pragma once
@@ -24,10 +28,12 @@ struct XState {
     double loss0, loss1;          // sum of squared residuals at w and at w_new (reduce_rows_kernel)
     real cgtol;
     int cg_iter, accepted;
-    // fused CG path (hv_tile_kernel, HV_CG_*): r^T r of every iteration, stop flag, buffer that holds the final r
+    // fused CG path (hv_tile_kernel, HV_CG_*): r^T r of every iteration, the iteration whose launch detected the
+    // stop (kCgRunning until then), buffer that holds the final r
     double rho_hist[kCgHistCap + 2];
-    int cg_done, r_parity;
+    int stop_it, r_parity;
 };
+constexpr int kCgRunning = 0x7fffffff;
 
 // partial-sum arrays: Pbase[slot * kMaxPartials + block]
 enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_LQ = 7,
@@ -372,7 +378,9 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     // thp[l*KP + pos]   = Theta(l, collog(pos)), POSITION order like the staged operand  (AR residual, phase 2)
     // both with the row stride KP so that a thread's 4 neighbouring columns are one aligned 16/32-byte read
 
-    if (MODE == HV_CG_STEP && st->cg_done) return;          // sticky stop: an earlier launch ended the CG
+    // sticky stop: an EARLIER launch ended the CG.  Launch `it` itself may store stop_it = it while some of its
+    // workgroups have not started yet; they read either kCgRunning or `it`, never a value below `it`.
+    if (MODE == HV_CG_STEP && st->stop_it < it) return;
 
     // ---- scalar prologue; Theta / lag set to LDS (their loads fly with the partials) ----
     real thr[kHvThetaRegs];
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             if (p.nlag > 0 && p.lambdaAR > 0) f += 0.5 * p.lambdaAR * ar2;   // trmf.cpp:94
             st->f = f; st->fnew = f; st->gnorm = gnorm; st->cgtol = cgtol; st->cg_rnorm = gnorm;
             st->cg_iter = 0; st->accepted = 0; st->rho_hist[0] = (double)ggr;
-            st->cg_done = stopped ? 1 : 0; st->r_parity = 0;
+            st->stop_it = stopped ? 0 : kCgRunning; st->r_parity = 0;
         }
     }
     if (nlag > 0) {
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         tmp = beta - (real)1.0;                                              // rf_tron.h:497
         if (blockIdx.x == 0 && tid == 0) {
             st->rho_hist[it] = rho_d;
-            if (stopped) { st->cg_done = 1; st->r_parity = it & 1; }
+            if (stopped) { st->stop_it = it; st->r_parity = it & 1; }
             else st->cg_iter = it + 1;                                       // nobody reads cg_iter during the solve
         }
     }
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
         st->cg_rnorm = gnorm;
         st->cg_iter = 0;
         st->accepted = 0;
-        st->cg_done = 0; st->r_parity = 0;
+        st->stop_it = kCgRunning; st->r_parity = 0;
     }
     const size_t N = (size_t)p.T * p.KP;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {

@@ -144,42 +144,53 @@ __global__ __launch_bounds__(256) void small_gram_reduce_kernel(const double *__
 // ---- shared-matrix solve: H[i][:] = GS^-1 b_i for every row (posv with n right-hand sides) -------------
 // Each workgroup first factorises the k x k matrix in LDS (upper Cholesky, val_type, as posv 'U'),
 // then every thread solves one row by forward / backward substitution; its vector lives in an LDS
-// column (conflict-free).  dynamic LDS = (k*k + 256*k) * sizeof(real)
+// column (conflict-free).  The workgroup size (= rows per workgroup, 64..256) is chosen by the host so
+// that the dynamic LDS, solve_shared_lds_bytes(), stays within the 64 KB every launch may use without a
+// function attribute: 256 rows up to k = 27 (fp64) / 51 (fp32), 64 rows at k = 64 fp64.
+__host__ __device__ inline size_t solve_shared_lds_bytes(int k, int rows_per_block) {
+    return ((size_t)k * k + (size_t)rows_per_block * k) * sizeof(real);
+}
+inline int solve_shared_rows_per_block(int k) {
+    for (int r : {256, 128, 64})
+        if (solve_shared_lds_bytes(k, r) <= 64 * 1024) return r;
+    return 0;       // cannot happen for k <= kMaxRank
+}
 __global__ __launch_bounds__(256) void solve_shared_kernel(const real *__restrict__ GS,
                                                            const real *__restrict__ Brows,
                                                            real *__restrict__ out, int rows, int k,
                                                            int KP, int NT) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ss_raw[];
+    const int nthr = (int)blockDim.x;                    // rows per workgroup
     real *U = reinterpret_cast<real *>(ss_raw);          // k x k
-    real *xs = U + k * k;                                // k x 256, xs[p * 256 + tid]
-    for (int e = threadIdx.x; e < k * k; e += 256) U[e] = GS[e];
+    real *xs = U + k * k;                                // k x nthr, xs[p * nthr + tid]
+    for (int e = threadIdx.x; e < k * k; e += nthr) U[e] = GS[e];
     __syncthreads();
     for (int j = 0; j < k; j++) {                        // same loop as theta_solve_kernel
         const real ajj = sqrt(U[j * k + j]);
         __syncthreads();
-        for (int c = j + threadIdx.x; c < k; c += 256) U[j * k + c] = (c == j) ? ajj : U[j * k + c] / ajj;
+        for (int c = j + threadIdx.x; c < k; c += nthr) U[j * k + c] = (c == j) ? ajj : U[j * k + c] / ajj;
         __syncthreads();
         for (int s = j + 1; s < k; s++) {
             const real ujs = U[j * k + s];
-            for (int c = s + threadIdx.x; c < k; c += 256) U[s * k + c] -= ujs * U[j * k + c];
+            for (int c = s + threadIdx.x; c < k; c += nthr) U[s * k + c] -= ujs * U[j * k + c];
         }
         __syncthreads();
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * nthr + threadIdx.x;
     if (i >= rows) return;
     real *x = xs + threadIdx.x;
-    for (int p = 0; p < k; p++) x[p * 256] = Brows[(size_t)i * KP + p];
+    for (int p = 0; p < k; p++) x[p * nthr] = Brows[(size_t)i * KP + p];
     for (int p = 0; p < k; p++) {                        // U^T z = b
-        real s = x[p * 256];
-        for (int q = 0; q < p; q++) s -= U[q * k + p] * x[q * 256];
-        x[p * 256] = s / U[p * k + p];
+        real s = x[p * nthr];
+        for (int q = 0; q < p; q++) s -= U[q * k + p] * x[q * nthr];
+        x[p * nthr] = s / U[p * k + p];
     }
     for (int p = k - 1; p >= 0; p--) {                   // U x = z
-        real s = x[p * 256];
-        for (int q = p + 1; q < k; q++) s -= U[p * k + q] * x[q * 256];
-        x[p * 256] = s / U[p * k + p];
+        real s = x[p * nthr];
+        for (int q = p + 1; q < k; q++) s -= U[p * k + q] * x[q * nthr];
+        x[p * nthr] = s / U[p * k + p];
     }
-    for (int p = 0; p < k; p++) out[(size_t)i * KP + colpos(p, NT)] = x[p * 256];
+    for (int p = 0; p < k; p++) out[(size_t)i * KP + colpos(p, NT)] = x[p * nthr];
 }
 
 }  // namespace trmf

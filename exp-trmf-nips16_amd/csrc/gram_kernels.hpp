@@ -601,193 +601,6 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
     }
 }
 
-// ---- F-solve, producer/consumer form (fp32) -----------------------------------------------------------
-// PMC of the quad kernel: MFMA pipe busy 37 %, VALU busy 40 %, but at 192 registers only two wavefronts
-// fit a SIMD and their matrix and vector phases rarely overlap.  Here a workgroup is TWO wavefronts
-// with different jobs and <= 128 registers each (4 wavefronts per SIMD):
-//   wave 0, producer: one gram_ring() stream over the workgroup's rows (MFMA + gathers); every finished
-//           Gram (+lambda) and rhs goes into one of kPcSlabs LDS slabs;
-//   wave 1, consumer: pulls each slab into the registers of one 16-lane row and, every four systems,
-//           runs quad_factor_solve() (VALU + ds_swizzle/DPP) and stores four rows of F.
-// Hand-off through two LDS counters (full / drained) with plain polling: the producer may run
-// kPcSlabs rows ahead, so neither side waits in steady state.  Every spin is bounded; on timeout the
-// workgroup raises *err (checked by the host) instead of hanging the device.
-constexpr int kPcSlabs = 2;
-constexpr int kPcRows = 16;         // item rows per workgroup
-constexpr int kPcSpinLimit = 1 << 22;
-#ifndef TRMF_PC_ROLE_SHIFT
-#define TRMF_PC_ROLE_SHIFT 1
-#endif
-constexpr int kPcRoleShift = TRMF_PC_ROLE_SHIFT;
-
-__device__ __forceinline__ bool pc_wait_ge(volatile int *cnt, int target, volatile int *abort_flag) {
-    int spins = 0;
-    while (*cnt < target) {
-        __builtin_amdgcn_s_sleep(4);
-        if (*abort_flag) return false;
-        if (++spins > kPcSpinLimit) { *abort_flag = 1; return false; }
-    }
-    return true;
-}
-
-// Stream over the non-empty rows among [r_lo, r_hi): row pointers come from LDS (sptr[i] = ptr[r_lo+i]).
-struct ChunkStream {
-    const volatile uint32_t *sptr;
-    int nrows;
-    uint32_t step;
-    __device__ __forceinline__ uint32_t at(int i) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)sptr[i]); }
-    __device__ __forceinline__ GramDesc first() const {
-        for (int r = 0; r < nrows; r++)
-            if (at(r + 1) > at(r)) return GramDesc{at(r), at(r + 1), r};
-        return GramDesc{0, 0, -1};
-    }
-    __device__ __forceinline__ void operator()(GramDesc &d) const {
-        if (d.row < 0) return;
-        d.e0 += step;
-        if (d.e0 < d.end) return;
-        int r = d.row + 1;
-        while (r < nrows && at(r + 1) == at(r)) r++;                   // skip empty rows (trmf.cpp:374)
-        if (r < nrows) d = GramDesc{at(r), at(r + 1), r};
-        else d = GramDesc{0, 0, -1};
-    }
-};
-
-template <int NT, int KMAX, int ABL = 0>
-__global__ __launch_bounds__(128, 4) void fsolve_pc_kernel(const uint32_t *__restrict__ ptr,
-                                                           const uint32_t *__restrict__ idx,
-                                                           const float *__restrict__ val,
-                                                           const float *__restrict__ X,
-                                                           float *__restrict__ F, uint32_t row_begin,
-                                                           uint32_t row_end, int k, float lambda,
-                                                           uint32_t zero_row, int *__restrict__ err) {
-    static_assert(sizeof(real) == 4, "producer/consumer F-solve is the fp32 path");
-    constexpr int KP = kTile * NT;
-    constexpr int SLABF = quad_slab_floats<NT>() + KP;               // Gram columns + rhs
-    __shared__ __attribute__((aligned(16))) float lds_slab[kPcSlabs][SLABF];
-    __shared__ uint32_t lds_ptr[kPcRows + 1];
-    __shared__ int lds_cnt[3];                                          // full, drained, abort
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int grp = lane >> 4, c = lane & 15;
-    const uint32_t r_lo = row_begin + blockIdx.x * (uint32_t)kPcRows;
-    if (r_lo >= row_end) return;
-    const int nrows = (int)min((uint32_t)kPcRows, row_end - r_lo);
-    if ((int)threadIdx.x <= nrows) lds_ptr[threadIdx.x] = ptr[r_lo + threadIdx.x];
-    if (threadIdx.x < 3) lds_cnt[threadIdx.x] = 0;
-    __syncthreads();                                                    // the only workgroup barrier
-    volatile int *full_cnt = &lds_cnt[0], *drain_cnt = &lds_cnt[1], *abort_flag = &lds_cnt[2];
-    typedef float f4 __attribute__((ext_vector_type(4)));
-
-    // Role assignment.  The dispatcher was observed to put wave 0 of successive 2-wave workgroups on
-    // SIMDs {0,1} and wave 1 on SIMDs {2,3}; a fixed wave->role map would then run every producer on
-    // two matrix pipes and every consumer on two VALUs (measured: 2x slower).  Alternating the roles
-    // with the workgroup index spreads both over all four SIMDs (speed only, never correctness).
-    const int swap = (int)((blockIdx.x >> kPcRoleShift) & 1u);
-#if defined(TRMF_PC_DEBUG)
-    if (lane == 0) {   // histogram of (role, SIMD) from HW_REG_HW_ID[5:4]
-        const int simd = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
-        atomicAdd(&err[1 + (wave ^ swap) * 4 + simd], 1);
-    }
-#endif
-    if ((wave ^ swap) == 0) {
-        // ------------------------------------------------ producer ------------------------------------------------
-        GramState<NT> st;
-        st.clear();
-        int produced = 0;
-        ChunkStream stream{lds_ptr, nrows, 4u * kRingDepth};
-        auto publish = [&](int /*row*/) {
-#pragma unroll
-            for (int q = 0; q < NT; q++) {
-                st.b[q] += __shfl_xor(st.b[q], 16, kWave);
-                st.b[q] += __shfl_xor(st.b[q], 32, kWave);
-            }
-            if (!pc_wait_ge(drain_cnt, produced - kPcSlabs + 1, abort_flag)) { st.clear(); return; }
-            float *S = lds_slab[produced % kPcSlabs];
-            int t = 0;
-#pragma unroll
-            for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-                for (int tj = ti; tj < NT; tj++, t++) {
-                    f4 v = st.acc[t];
-                    if (ti == tj) {
-#pragma unroll
-                        for (int r = 0; r < 4; r++)   // + lambda (trmf.cpp:393); pad rows: unit diagonal
-                            if (c == 4 * grp + r) v[r] += (kTile * ti + c < k) ? lambda : 1.0f;
-                    }
-                    *reinterpret_cast<f4 *>(&S[quad_slab_col_offset<NT>(tj) + c * (kTile * (tj + 1) + 4) + kTile * ti + 4 * grp]) = v;
-                }
-            if (grp == 0) {
-#pragma unroll
-                for (int q = 0; q < NT; q++) S[quad_slab_floats<NT>() + kTile * q + c] = st.b[q];
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            produced++;
-            if (lane == 0) *full_cnt = produced;
-            st.clear();
-        };
-        float nowq[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) nowq[q] = 0;
-        gram_ring<NT, kRingDepth, !(ABL & 1), false>(st, idx, val, X, zero_row, 4u, lane, nowq, stream.first(), stream, publish);
-    } else {
-        // ------------------------------------------------ consumer ------------------------------------------------
-        float areg[NT][KMAX];
-        float bz[NT];
-        auto reset = [&]() {
-#pragma unroll
-            for (int q = 0; q < NT; q++) {
-                bz[q] = 0;
-#pragma unroll
-                for (int s = 0; s < KMAX; s++) areg[q][s] = (s == kTile * q + c) ? 1.0f : 0.0f;   // idle rows: identity
-            }
-        };
-        reset();
-        int consumed = 0;
-        uint32_t myrow = 0;
-        bool mine = false;
-        for (int r = 0; r < nrows; r++) {
-            const uint32_t a0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ptr[r]);
-            const uint32_t a1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_ptr[r + 1]);
-            const bool last = (r == nrows - 1);
-            if (a1 > a0) {
-                if (!pc_wait_ge(full_cnt, consumed + 1, abort_flag)) break;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const float *S = lds_slab[consumed % kPcSlabs];
-                if (grp == (consumed & 3)) {
-                    mine = true;
-                    myrow = r_lo + (uint32_t)r;
-#pragma unroll
-                    for (int q = 0; q < NT; q++) {
-                        bz[q] = S[quad_slab_floats<NT>() + kTile * q + c];
-#pragma unroll
-                        for (int s4 = 0; s4 < KMAX / 4; s4++) {
-                            if (4 * s4 <= kTile * q + 15) {
-                                const f4 v = *reinterpret_cast<const f4 *>(&S[quad_slab_col_offset<NT>(q) + c * (kTile * (q + 1) + 4) + 4 * s4]);
-                                areg[q][4 * s4 + 0] = v[0]; areg[q][4 * s4 + 1] = v[1];
-                                areg[q][4 * s4 + 2] = v[2]; areg[q][4 * s4 + 3] = v[3];
-                            }
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                consumed++;
-                if (lane == 0) *drain_cnt = consumed;
-            }
-            if (consumed > 0 && ((consumed & 3) == 0 || last) && __builtin_amdgcn_readfirstlane((int)__any(mine))) {
-                float x[NT];
-                quad_factor_solve<NT, KMAX, (ABL & 2) ? 6 : 0>(areg, bz, x, c);
-                if (mine) {
-                    RealVec<NT> o;
-#pragma unroll
-                    for (int q = 0; q < NT; q++) o.v[q] = (kTile * q + c < k) ? x[q] : 0.0f;
-                    *reinterpret_cast<RealVec<NT> *>(F + (size_t)myrow * KP + NT * c) = o;
-                }
-                mine = false;
-                reset();
-            }
-        }
-    }
-    if (lane == 0 && *abort_flag) *err = 1;
-}
 #endif  // TRMF_F32
 
 // ---- X-side Gram cache: one wavefront per timestamp row --------------------------------------------

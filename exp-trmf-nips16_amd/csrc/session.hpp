@@ -135,9 +135,7 @@ struct TrmfSessionImpl {
         if (const char *e = getenv("TRMF_FSOLVE")) {
             const std::string m(e);
             use_quad = use_quad && m != "wave";
-            use_pc = sizeof(real) == 4 && m == "pc";
         }
-        if (dev_err.alloc(16)) return kFail;
         if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
         if (Y->type == TRMF_SPARSE) host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -194,6 +192,9 @@ struct TrmfSessionImpl {
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
         const int npairs = nlag * (nlag + 1) / 2 + nlag;
         if (theta_part.alloc((size_t)k * nchunk * std::max(npairs, 1))) return kFail;
+        if (nlag && (allow_dyn_lds(theta_gram_kernel, theta_gram_lds(), "Theta Gram (max lag too large)") ||
+                     allow_dyn_lds(theta_solve_kernel, theta_solve_lds(), "Theta solve (too many lags)")))
+            return kFail;
 
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
@@ -279,35 +280,8 @@ struct TrmfSessionImpl {
 #endif
         return 0;
     }
-    template <int NT_, int KMAX_> int launch_fsolve_pc(uint32_t rb, uint32_t re) {
-        const uint32_t rows = re - rb;
-        if (rows == 0) return 0;
-#if defined(TRMF_F32)
-        const dim3 grid((rows + kPcRows - 1) / kPcRows), block(128);
-#define TRMF_LAUNCH_PC(ABL)                                                                            \
-        hipLaunchKernelGGL((fsolve_pc_kernel<NT_, KMAX_, ABL>), grid, block, 0, stream, Yc_ptr.p,      \
-                           Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T, dev_err.p)
-#if defined(TRMF_ABLATION)
-        if (NT_ == 3 && KMAX_ == 40 && dbg_flags) {
-            switch (dbg_flags) {
-                case 1: TRMF_LAUNCH_PC(1); break;
-                case 2: TRMF_LAUNCH_PC(2); break;
-                default: TRMF_LAUNCH_PC(3); break;
-            }
-            return 0;
-        }
-#endif
-        TRMF_LAUNCH_PC(0);
-#undef TRMF_LAUNCH_PC
-#endif
-        return 0;
-    }
-    // fp32: four systems per wavefront (fsolve_quad_kernel).  TRMF_FSOLVE=pc selects the experimental
-    // producer/consumer wavefront pairs (correct, currently slower: DESIGN.md 4.2); fp64 or
-    // TRMF_FSOLVE=wave: one system per wavefront
+    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64 or TRMF_FSOLVE=wave: one system per wavefront
     bool use_quad = sizeof(real) == 4;
-    bool use_pc = false;
-    DevBuf<int> dev_err;
     // X-side Gram build across ranks: sharded rows + all-gather of G (64 MB at config 3) pays only when a
     // rank's share of the gather is cheaper than the rows it no longer computes -- true on 8 GPUs, not on 2.
     // First call measures (kernel and gather time of every rank, exchanged through the communicator so that
@@ -320,19 +294,7 @@ struct TrmfSessionImpl {
     int fsolve(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
-        if (use_pc) {
-            switch (KMAX) {
-                case 8:  launch_fsolve_pc<1, 8>(rb, re); break;
-                case 16: launch_fsolve_pc<1, 16>(rb, re); break;
-                case 24: launch_fsolve_pc<2, 24>(rb, re); break;
-                case 32: launch_fsolve_pc<2, 32>(rb, re); break;
-                case 40: launch_fsolve_pc<3, 40>(rb, re); break;
-                case 48: launch_fsolve_pc<3, 48>(rb, re); break;
-                case 56: launch_fsolve_pc<4, 56>(rb, re); break;
-                case 64: launch_fsolve_pc<4, 64>(rb, re); break;
-                default: set_error("unsupported rank"); return kFail;
-            }
-        } else if (use_quad) {
+        if (use_quad) {
             switch (KMAX) {
                 case 8:  launch_fsolve_quad<1, 8>(rb, re); break;
                 case 16: launch_fsolve_quad<1, 16>(rb, re); break;
@@ -491,9 +453,9 @@ struct TrmfSessionImpl {
         if (y_times_factor(true, W.p, Bf.p, dense ? 0u : rb, dense ? (uint32_t)n : re)) return kFail;   // Y^T W
         small_gram(W.p, T, (real)lambdaI, GSf.p);                                                       // W^T W + lambda I
         if (re > rb) {
-            const size_t lds = ((size_t)k * k + 256 * (size_t)k) * sizeof(real);
-            hipLaunchKernelGGL(solve_shared_kernel, dim3((re - rb + 255) / 256), dim3(256), lds, stream, GSf.p,
-                               Bf.p + (size_t)rb * KP, H.p + (size_t)rb * KP, (int)(re - rb), k, KP, NT);
+            const int rpw = solve_shared_rows_per_block(k);            // 64..256 rows per workgroup: LDS <= 64 KB
+            hipLaunchKernelGGL(solve_shared_kernel, dim3((re - rb + rpw - 1) / rpw), dim3(rpw), solve_shared_lds_bytes(k, rpw),
+                               stream, GSf.p, Bf.p + (size_t)rb * KP, H.p + (size_t)rb * KP, (int)(re - rb), k, KP, NT);
         }
         TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
         TRMF_HIP_CHECK(hipGetLastError());
@@ -600,15 +562,27 @@ struct TrmfSessionImpl {
         return 0;
     }
 
+    // Dynamic LDS above the 64 KB every launch may use needs an explicit opt-in per kernel (gfx950: up to 160 KB
+    // per workgroup); anything larger is an unsupported problem, reported instead of a failed launch.
+    static constexpr size_t kLdsDefault = 64 * 1024, kLdsMax = 160 * 1024;
+    template <typename Fn> int allow_dyn_lds(Fn fn, size_t bytes, const char *what) {
+        if (bytes <= kLdsDefault) return 0;
+        if (bytes > kLdsMax) { set_error(std::string(what) + ": needs more than 160 KB of LDS per workgroup"); return kFail; }
+        TRMF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        return 0;
+    }
+
     // ---- Theta solve (trmf.cpp:677-689 -> 455-484) ------------------------------------------------------
+    size_t theta_gram_lds() const { return (size_t)(kThetaChunk + midx) * sizeof(real); }
+    size_t theta_solve_lds() const { return (size_t)(nlag * nlag + nlag) * sizeof(real); }
     int theta_solve() {
         if (nlag == 0) return 0;
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
         const int npairs = nlag * (nlag + 1) / 2 + nlag;
-        const size_t lds1 = (size_t)(kThetaChunk + midx) * sizeof(real);
+        const size_t lds1 = theta_gram_lds();
         hipLaunchKernelGGL(theta_gram_kernel, dim3(k, nchunk), dim3(256), lds1, stream, W.p, T, KP, lag_set.p,
                            nlag, midx, npairs, theta_part.p);
-        const size_t lds2 = (size_t)(nlag * nlag + nlag) * sizeof(real);
+        const size_t lds2 = theta_solve_lds();
         hipLaunchKernelGGL(theta_solve_kernel, dim3(k), dim3(64), lds2, stream, theta_part.p, nchunk, nlag,
                            npairs, lambdaLag, theta.p);
         TRMF_HIP_CHECK(hipGetLastError());
@@ -687,16 +661,6 @@ struct TrmfSessionImpl {
 
     int sync() {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        int e = 0;
-        TRMF_HIP_CHECK(hipMemcpy(&e, dev_err.p, sizeof(int), hipMemcpyDeviceToHost));
-#if defined(TRMF_PC_DEBUG)
-        {
-            int h[16];
-            TRMF_HIP_CHECK(hipMemcpy(h, dev_err.p, sizeof h, hipMemcpyDeviceToHost));
-            fprintf(stderr, "pc placement: producer simd[0..3] = %d %d %d %d ; consumer = %d %d %d %d\n", h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
-        }
-#endif
-        if (e) { set_error("F-solve producer/consumer hand-off timed out (device error flag set)"); return kFail; }
         return 0;
     }
 

@@ -1,0 +1,127 @@
+"""GPU (-m gpu): BASELINE.json's configurations at their FULL sizes against the oracle.
+
+* config 3 (100k x 10k, 1 %, k=40, |L|=16, fp32): 2 ALS iterations vs the C restatement on all host
+  cores -- the headline size itself, not only a scaled-down shape.
+* config 5 (1M x 50k, 0.1 %, k=64, |L|=32, fp64) on ONE GPU: 1 ALS iteration vs the restatement at the
+  fp64 gates, plus size-independent properties.
+* the fused CG (one launch per iteration, multi-wave grids) against the unfused kernels.
+* the paper scripts' own shape (dense, missing=0, k=60 / 40, 48 lags up to 191).
+Tolerances: helpers.TOL."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_py as O
+import trmf
+from helpers import TOL, make_model, relfro, relmax
+from trmf import session, synth
+
+pytestmark = pytest.mark.gpu
+NCPU = os.cpu_count() or 8
+
+
+def test_config3_full_size_vs_oracle():
+    cfg = synth.CONFIGS['c3']
+    p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float32, seed=0)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], cfg['k'], seed=0)
+    iters = 2
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    log = O.train_port(p['Y'], p['lag_set'], W, H, Th, synth.HYPER, max_iter=iters, threads=NCPU)
+    model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+    with session.Session(p['Y'], model, missing=True, **synth.HYPER) as s:
+        s.run(iters); st = s.stats(iters); s.download()
+    Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
+    Jp = O.objective(p['Y'], p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
+    cg_o, cg_p = [l['cg_iter'] for l in log], [x['cg_iter'] for x in st]
+    print('c3 full size: J oracle %.10g gpu %.10g rel %.2e; relfro W %.2e H %.2e Th %.2e; CG oracle %s gpu %s' % (
+        Jo, Jp, abs(Jp - Jo) / Jo, relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th), cg_o, cg_p))
+    assert abs(Jp - Jo) / Jo < 1e-5
+    assert relfro(model.H, H) < 1e-3 and relfro(model.W, W) < 1e-3
+    assert all(abs(a - b) <= 1 for a, b in zip(cg_o, cg_p))
+
+
+def test_config5_full_size_single_gpu_vs_oracle():
+    """1M x 50k, 0.1 %, k=64, |L|=32, fp64 on one GPU (HBM capacity + the fp64 rank-64 kernels + T = 50k in
+    the CG): one ALS iteration vs the restatement on all host cores, fp64 gates."""
+    try:
+        avail_gb = os.sysconf('SC_AVPHYS_PAGES') * os.sysconf('SC_PAGE_SIZE') / 2 ** 30
+    except (ValueError, OSError):
+        avail_gb = 1e9
+    if avail_gb < 48:
+        pytest.skip('needs ~40 GB of host memory to generate config 5')
+    cfg = synth.CONFIGS['c5']
+    p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float64, seed=0)
+    Y = p['Y']
+    m0 = synth.initial_model(Y, p['lag_set'], cfg['k'], seed=0)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    log = O.train_port(Y, p['lag_set'], W, H, Th, synth.HYPER, max_iter=1, threads=NCPU)
+    model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+    with session.Session(Y, model, missing=True, **synth.HYPER) as s:
+        s64 = 8
+        assert abs(s.fsolve_bytes() - (Y.nnz * (4 + s64 + 64 * s64) + (cfg['n'] + 1) * 8 + cfg['n'] * 64 * s64)) < 1
+        s.run(1); st = s.stats(1); Jdev = s.objective(); s.download()
+        s.run(2); st2 = s.stats(2); J3 = s.objective()
+    Jo = O.objective(Y, p['lag_set'], W, H, Th, synth.HYPER)
+    Jp = O.objective(Y, p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
+    print('c5 full size: J oracle %.12g gpu %.12g (device %.12g) rel %.2e; relmax H %.2e W %.2e; CG oracle %s gpu %s; ms F %.2f X %.2f' % (
+        Jo, Jp, Jdev, abs(Jp - Jo) / Jo, relmax(model.H, H), relmax(model.W, W), [l['cg_iter'] for l in log],
+        [x['cg_iter'] for x in st], st[0]['ms_F'], st[0]['ms_X']))
+    assert relmax(model.H, H) < 1e-6 and relmax(model.W, W) < 1e-6
+    assert abs(Jp - Jo) / Jo < 1e-8 and abs(Jdev - Jp) / Jp < 1e-10
+    assert [x['cg_iter'] for x in st] == [l['cg_iter'] for l in log]
+    assert all(x['accepted'] == 1 for x in st + st2) and J3 < Jdev       # later iterations keep descending
+
+
+@pytest.mark.parametrize('dtype,k,T,nlag', [(np.float64, 40, 27000, 4), (np.float32, 40, 60000, 16), (np.float64, 24, 20000, 6)])
+def test_fused_cg_equals_unfused_on_multiwave_grids(dtype, k, T, nlag, monkeypatch):
+    """More CG tiles than the chip holds at once (one workgroup per tile: 2250 / 2400 / 1539 tiles vs <= 512
+    resident), every solve stopping early on eps_cg, so each solve has ONE stopping launch followed by launches
+    that must do nothing: the fused path (hv_tile_kernel) must reproduce the unfused kernels (TRMF_NO_HV_TILE)
+    -- same arithmetic, same stop iteration."""
+    p = synth.sparse_problem(n=50, T=T, k=k, nlag=nlag, density=0.04, dtype=dtype, seed=13)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], k, seed=13)
+    iters = 3
+
+    def run():
+        model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+        with session.Session(p['Y'], model, missing=True, **synth.HYPER) as s:
+            s.run(iters); st = s.stats(iters); s.download()
+        return model, [x['cg_iter'] for x in st]
+
+    fused, cg_f = run()
+    monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
+    plain, cg_u = run()
+    assert all(1 <= c < 20 for c in cg_f), cg_f                 # stopped by eps_cg, not by the iteration cap
+    tol = TOL[np.dtype(dtype).name]
+    print('fused vs unfused: CG %s / %s, relmax W %.2e H %.2e' % (cg_f, cg_u, relmax(fused.W, plain.W), relmax(fused.H, plain.H)))
+    if dtype == np.float64:
+        assert cg_f == cg_u
+        assert relmax(fused.W, plain.W) < tol['factor'] and relmax(fused.H, plain.H) < tol['factor']
+    else:
+        assert all(abs(a - b) <= 1 for a, b in zip(cg_f, cg_u))
+        assert relfro(fused.W, plain.W) < tol['factor'] and relfro(fused.H, plain.H) < tol['factor']
+
+
+PAPER_LAGS = list(range(1, 25)) + list(range(7 * 24, 8 * 24))          # run_electricity.py:13, run_traffic.py:13
+
+
+@pytest.mark.parametrize('T,n,k,hyper', [
+    (6000, 370, 60, dict(lambdaI=0.5, lambdaAR=125.0, lambdaLag=2.0)),        # run_electricity.py:9-25
+    (4000, 963, 40, dict(lambdaI=2.0, lambdaAR=625.0, lambdaLag=0.5)),        # run_traffic.py:9-25
+])
+def test_paper_script_shape_full_observation(T, n, k, hyper):
+    """The shape both paper scripts train at: dense Y, missing=0, fp64, k=60 (electricity) / 40 (traffic), 48 lags
+    {1..24} u {168..191} (max lag 191 -> unfused CG, 148 KB-class LDS requests of the full-path kernels), vs the
+    restatement at the fp64 gates.  T is shortened (the real series have 26 304 / 10 560 timestamps)."""
+    d = trmf.Model.syn_gen(T, n, k, PAPER_LAGS, seed=1, dtype=np.float64)
+    Y = np.ascontiguousarray(d['Y'] + 0.05 * np.random.RandomState(1).randn(T, n))
+    m0 = trmf.Model.initialize(Y, PAPER_LAGS, k, seed=0)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=3, missing=False, threads=NCPU)
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    trmf.train(Y, model, max_iter=3, missing=False, **hyper)
+    print('paper shape k=%d: relmax W %.2e H %.2e Th %.2e' % (k, relmax(model.W, W), relmax(model.H, H), relmax(model.lag_val, Th)))
+    assert relmax(model.W, W) < 1e-6 and relmax(model.H, H) < 1e-6 and relmax(model.lag_val, Th) < 1e-5
+    J = lambda A, B: 0.5 * np.sum((Y - A @ B.T) ** 2)
+    assert abs(J(model.W, model.H) - J(W, H)) / J(W, H) < 1e-8

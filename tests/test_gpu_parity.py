@@ -153,10 +153,10 @@ def test_objective_parity_fp32_10_iterations_config2_shape():
     assert relfro(model.W, W) < 1e-3 and relfro(model.H, H) < 1e-3
 
 
-@pytest.mark.parametrize('form', ['wave', 'pc'])
+@pytest.mark.parametrize('form', ['wave'])
 def test_alternative_fsolve_forms_match(form, monkeypatch):
-    """fp32 F-solve through the other two kernels behind TRMF_FSOLVE (one wavefront per row -- the fp64 path's
-    kernel -- and the experimental producer/consumer pairs): same systems, same answers as the default quad form."""
+    """fp32 F-solve through the other kernel behind TRMF_FSOLVE (one wavefront per row): same systems, same
+    answers as the default quad form."""
     p = synth.sparse_problem(n=900, T=400, k=40, nlag=4, density=0.08, dtype=np.float32, seed=3)
     m0 = synth.initial_model(p['Y'], p['lag_set'], 40, seed=3)
     big = 10 ** 6
