@@ -25,6 +25,7 @@
 #include "full_kernels.hpp"
 #include "common.hpp"
 #include "gram_kernels.hpp"
+#include "resident_kernels.hpp"
 #include "theta_kernels.hpp"
 
 namespace trmf {
@@ -39,6 +40,7 @@ template <typename T> struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     int alloc(size_t count, bool zero = true) {
         release();
         n = count;
@@ -126,6 +128,11 @@ struct TrmfSessionImpl {
         return dst.upload(tmp.data(), count);
     }
 
+    // Host copies of the two pointer arrays (8 bytes per row/column): row partitions, the byte model of
+    // fsolve_bytes(), and the merged pointers of append_rows() are derived from them.
+    std::vector<uint64_t> host_row_ptr, host_col_ptr;
+    double ysq_acc = 0;          // sum of y^2 over every entry uploaded so far (fp64)
+
     int create(const PyMatrix *Y, const uint32_t *lags, uint32_t lag_size, const PyMatrix *Wm,
                const PyMatrix *Hm, const PyMatrix *LVm) {
         T = (int)Y->rows; n = (int)Y->cols; k = (int)Wm->cols; nnz = Y->nnz;
@@ -137,57 +144,86 @@ struct TrmfSessionImpl {
             use_quad = use_quad && m != "wave";
         }
         if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
-        if (Y->type == TRMF_SPARSE) host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
 
         dense = Y->type != TRMF_SPARSE;
         if (!dense) {
+            host_row_ptr.assign(Y->row_ptr, Y->row_ptr + (size_t)T + 1);
+            host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
             if (upload_ptr32(Yr_ptr, Y->row_ptr, (size_t)T + 1)) return kFail;
             if (Yr_idx.upload(Y->col_idx, nnz)) return kFail;
             if (Yr_val.upload((const real *)Y->val_t, nnz)) return kFail;
             if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
             if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
             if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
-            {
-                const real *v = (const real *)Y->val_t;
-                double acc = 0;
-                for (uint64_t e = 0; e < nnz; e++) acc += (double)v[e] * (double)v[e];
-                // full: do_dot_product(Y, Y) in val_type (trmf.cpp:184); observed-entries path: kept in double,
-                // it is the constant of  loss(w) = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i)
-                trYTY = full ? (double)(real)acc : acc;
-            }
+            ysq_acc = sum_squares((const real *)Y->val_t, nnz);
         } else {
             // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC
-            const real *v = (const real *)Y->val;
-            const bool rowmajor = Y->type == TRMF_DENSE_ROWMAJOR;
-            std::vector<real> tn((size_t)T * n), nt((size_t)T * n);
-            double acc = 0;
-            for (int j = 0; j < T; j++)
-                for (int i = 0; i < n; i++) {
-                    const real y = rowmajor ? v[(size_t)j * n + i] : v[(size_t)i * T + j];
-                    tn[(size_t)j * n + i] = y; nt[(size_t)i * T + j] = y;
-                    acc += (double)y * (double)y;
-                }
-            trYTY = (double)(real)acc;
-            if (Yd_tn.upload(tn.data(), tn.size()) || Yd_nt.upload(nt.data(), nt.size())) return kFail;
+            std::vector<real> tn;
+            ysq_acc = dense_rows_to_rowmajor(Y, tn);
+            if (Yd_tn.upload(tn.data(), tn.size()) || Yd_nt.alloc((size_t)T * n, false)) return kFail;
+            launch_transpose(Yd_tn.p, T, n, Yd_nt.p);
         }
+        set_trYTY();
         if (lag_set.upload(lags, nlag)) return kFail;
         if (upload_padded(W, (const real *)Wm->val, T)) return kFail;
         if (upload_padded(H, (const real *)Hm->val, n)) return kFail;
         if (theta.upload((const real *)LVm->val, (size_t)nlag * k)) return kFail;
+        if (xstate.alloc(1) || log.alloc(kLogCap)) return kFail;
+        if (full && (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
+                     sgram_part.alloc((size_t)kSmallGramBlocks * k * k)))
+            return kFail;
+        if (alloc_time_scratch()) return kFail;
 
-        const size_t NV = (size_t)T * KP;
-        if (full) {
-            const size_t big = (size_t)std::max(T, n);
-            if (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
-                sgram_part.alloc((size_t)kSmallGramBlocks * k * k) ||
-                (dense && gemm_part.alloc((size_t)kGemmChunks * big * KP)))
-                return kFail;
+        events.resize(kEventRing);
+        for (auto &e : events) {
+            hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
+            for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
+        for (hipEvent_t *ev : {&gx0, &gx1, &gx2}) TRMF_HIP_CHECK(hipEventCreate(ev));
+        if (gramx_times.alloc((size_t)2 * comm->world)) return kFail;
+        if (comm->world == 1) gramx_mode = kGramxShard;              // nothing to decide
+        if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
+        TRMF_HIP_CHECK(hipDeviceSynchronize());
+        return 0;
+    }
+
+    static double sum_squares(const real *v, uint64_t count) {
+        double acc = 0;
+        for (uint64_t e = 0; e < count; e++) acc += (double)v[e] * (double)v[e];
+        return acc;
+    }
+    // rows of a dense PyMatrix (either memory order) as one row-major block; returns the sum of squares
+    static double dense_rows_to_rowmajor(const PyMatrix *Y, std::vector<real> &tn) {
+        const size_t R = Y->rows, C = Y->cols;
+        const real *v = (const real *)Y->val;
+        tn.resize(R * C);
+        double acc = 0;
+        if (Y->type == TRMF_DENSE_ROWMAJOR) {
+            std::memcpy(tn.data(), v, R * C * sizeof(real));
+            for (size_t e = 0; e < R * C; e++) acc += (double)v[e] * (double)v[e];
+        } else {
+            for (size_t j = 0; j < R; j++)
+                for (size_t i = 0; i < C; i++) { const real y = v[i * R + j]; tn[j * C + i] = y; acc += (double)y * (double)y; }
+        }
+        return acc;
+    }
+    void launch_transpose(const real *src, int rows, int cols, real *dst) {
+        if (rows > 0 && cols > 0)
+            hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, stream, src, rows, cols, dst);
+    }
+    // full: do_dot_product(Y, Y) in val_type (trmf.cpp:184); observed-entries path: kept in double, it is the
+    // constant of  loss(w) = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i)
+    void set_trYTY() { trYTY = (full || dense) ? (double)(real)ysq_acc : ysq_acc; xp.trYTY = trYTY; }
+
+    // Everything whose size depends on the number of timestamps T (and the row partitions): called by create()
+    // and again by append_rows().
+    int alloc_time_scratch() {
+        const size_t NV = (size_t)T * KP;
+        if (full && dense && gemm_part.alloc((size_t)kGemmChunks * (size_t)std::max(T, n) * KP)) return kFail;
         if (G.alloc((full ? 1 : (size_t)T * k * k) + kHvGramPad) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
             d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || r1.alloc(NV) || Hd1.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
-            lossrow.alloc(T) || xstate.alloc(1) ||
-            log.alloc(kLogCap))
+            lossrow.alloc(T))
             return kFail;
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
         const int npairs = nlag * (nlag + 1) / 2 + nlag;
@@ -199,6 +235,7 @@ struct TrmfSessionImpl {
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
         nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
+        tile_TI = 0; nbt = 1;
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
             int TI = hv_tile_rows(k);
             if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
@@ -217,24 +254,86 @@ struct TrmfSessionImpl {
 
         fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1);
         if (!dense) {
-            partition_by_nnz<size_t>((uint64_t)n, Y->col_ptr, comm->world, fbounds.data());
-            partition_by_nnz<size_t>((uint64_t)T, Y->row_ptr, comm->world, xbounds.data());
+            partition_by_nnz<uint64_t>((uint64_t)n, host_col_ptr.data(), comm->world, fbounds.data());
+            partition_by_nnz<uint64_t>((uint64_t)T, host_row_ptr.data(), comm->world, xbounds.data());
         } else {
             for (int r = 0; r <= comm->world; r++) {
                 fbounds[r] = (uint64_t)n * r / comm->world;
                 xbounds[r] = (uint64_t)T * r / comm->world;
             }
         }
+        return 0;
+    }
 
-        events.resize(kEventRing);
-        for (auto &e : events) {
-            hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
-            for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
+    // ---- append new timestamps (trmf_session_append_rows; the rolling-window caller trmf.py:303-329) ---------------
+    // Ynew: Tn x n block of NEW timestamps, same storage class as the session's Y.  Only that block (plus, for a
+    // sparse Y, one 4-byte pointer per item) crosses PCIe: the CSR gains rows at its end, the CSC -- whose columns
+    // each gain entries at their tails -- is rebuilt on the device from the old CSC and the block's CSC, a dense Y's
+    // n x T copy is re-strided on the device, and W is extended by the AR recursion with the current Theta
+    // (Model.latent_forecast, trmf.py:170-181, the reference's warm start :237-246).  H and Theta are kept.
+    // The iteration counter restarts (a new train() call in the reference, trmf.cpp:647).
+    int append_rows(const PyMatrix *Yn) {
+        const int Tn = (int)Yn->rows, T0 = T;
+        if ((int)Yn->cols != n) { set_error("append_rows: column count differs from the session's"); return kFail; }
+        if ((Yn->type != TRMF_SPARSE) != dense) { set_error("append_rows: storage class (sparse/dense) differs from the session's"); return kFail; }
+        if ((uint64_t)(T0 + Tn + 1) >= (1ull << 24) || (uint64_t)(T0 + Tn + 1) * KP * sizeof(real) > 0xffffffffull ||
+            nnz + Yn->nnz >= (1ull << 32)) { set_error("append_rows: problem would exceed 32-bit device indices"); return kFail; }
+        if (Tn <= 0) return 0;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        const int T1 = T0 + Tn;
+        if (!dense) {
+            const uint64_t nz0 = nnz, nzn = Yn->nnz, nz1 = nz0 + nzn;
+            // CSR: old rows keep their place, the block's rows follow
+            for (int i = 1; i <= Tn; i++) host_row_ptr.push_back(nz0 + Yn->row_ptr[i]);
+            DevBuf<uint32_t> ptr2, idx2; DevBuf<real> val2;
+            if (upload_ptr32(ptr2, (const size_t *)host_row_ptr.data(), (size_t)T1 + 1) || idx2.alloc(nz1, false) || val2.alloc(nz1, false)) return kFail;
+            TRMF_HIP_CHECK(hipMemcpyAsync(idx2.p, Yr_idx.p, nz0 * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            TRMF_HIP_CHECK(hipMemcpyAsync(val2.p, Yr_val.p, nz0 * sizeof(real), hipMemcpyDeviceToDevice, stream));
+            if (nzn) {
+                TRMF_HIP_CHECK(hipMemcpyAsync(idx2.p + nz0, Yn->col_idx, nzn * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                TRMF_HIP_CHECK(hipMemcpyAsync(val2.p + nz0, Yn->val_t, nzn * sizeof(real), hipMemcpyHostToDevice, stream));
+            }
+            // CSC: column j = its old entries, then the block's entries of that column (timestamps shifted by T0)
+            std::vector<uint32_t> np32((size_t)n + 1);
+            for (int j = 0; j <= n; j++) { host_col_ptr[j] += Yn->col_ptr[j]; np32[j] = (uint32_t)host_col_ptr[j]; }
+            DevBuf<uint32_t> cptr2, cidx2, wptr, widx; DevBuf<real> cval2, wval;
+            if (cptr2.upload(np32.data(), np32.size()) || cidx2.alloc(nz1, false) || cval2.alloc(nz1, false) ||
+                upload_ptr32(wptr, Yn->col_ptr, (size_t)n + 1) || widx.upload(Yn->row_idx, nzn) || wval.upload((const real *)Yn->val, nzn))
+                return kFail;
+            hipLaunchKernelGGL(csc_append_kernel, dim3((n + 3) / 4), dim3(256), 0, stream, Yc_ptr.p, Yc_idx.p, Yc_val.p, wptr.p, widx.p,
+                               wval.p, cptr2.p, cidx2.p, cval2.p, n, (uint32_t)T0);
+            TRMF_HIP_CHECK(hipGetLastError());
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+            Yr_ptr.swap(ptr2); Yr_idx.swap(idx2); Yr_val.swap(val2);
+            Yc_ptr.swap(cptr2); Yc_idx.swap(cidx2); Yc_val.swap(cval2);
+            ysq_acc += sum_squares((const real *)Yn->val_t, nzn);
+            nnz = nz1;
+        } else {
+            std::vector<real> blk;
+            ysq_acc += dense_rows_to_rowmajor(Yn, blk);
+            DevBuf<real> tn2, nt2;
+            if (tn2.alloc((size_t)T1 * n, false) || nt2.alloc((size_t)T1 * n, false)) return kFail;
+            TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p, Yd_tn.p, (size_t)T0 * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
+            TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p + (size_t)T0 * n, blk.data(), blk.size() * sizeof(real), hipMemcpyHostToDevice, stream));
+            launch_transpose(tn2.p, T1, n, nt2.p);
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+            Yd_tn.swap(tn2); Yd_nt.swap(nt2);
+            nnz = (uint64_t)T1 * n;
         }
-        for (hipEvent_t *ev : {&gx0, &gx1, &gx2}) TRMF_HIP_CHECK(hipEventCreate(ev));
-        if (gramx_times.alloc((size_t)2 * comm->world)) return kFail;
-        if (comm->world == 1) gramx_mode = kGramxShard;              // nothing to decide
-        if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
+        {   // W: T0 rows kept, Tn rows rolled out by the AR model, one all-zero row at the end
+            DevBuf<real> W2;
+            if (W2.alloc((size_t)(T1 + 1) * KP)) return kFail;
+            TRMF_HIP_CHECK(hipMemcpyAsync(W2.p, W.p, (size_t)T0 * KP * sizeof(real), hipMemcpyDeviceToDevice, stream));
+            hipLaunchKernelGGL(latent_forecast_kernel, dim3(1), dim3(64), 0, stream, W2.p, T0, T1, KP, NT, k, lag_set.p, nlag, theta.p);
+            TRMF_HIP_CHECK(hipGetLastError());
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+            W.swap(W2);
+        }
+        T = T1;
+        set_trYTY();
+        iter = 0;
+        if (gramx_mode != kGramxReplicate && comm->world > 1 && !getenv("TRMF_GRAMX")) { gramx_mode = kGramxMeasure; gramx_calls = 0; }
+        if (alloc_time_scratch()) return kFail;
         TRMF_HIP_CHECK(hipDeviceSynchronize());
         return 0;
     }
@@ -707,7 +806,6 @@ struct TrmfSessionImpl {
 
     // algorithmic bytes of one F-solve launch on this rank
     double fsolve_bytes() const { return bytes_for_rows(fbounds[comm->rank], fbounds[comm->rank + 1]); }
-    std::vector<uint64_t> host_col_ptr;   // kept for fsolve_bytes
     double bytes_for_rows(uint64_t rb, uint64_t re) const {
         const double sz = sizeof(real);
         const double nz = host_col_ptr.empty() ? 0.0 : (double)(host_col_ptr[re] - host_col_ptr[rb]);

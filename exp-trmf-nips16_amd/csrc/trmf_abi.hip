@@ -183,6 +183,12 @@ int32_t trmf_session_log_norms(TrmfSession *s, int32_t on) {
     return 0;
 }
 int32_t trmf_session_sync(TrmfSession *s) { return s ? IMPL(s)->sync() : kFail; }
+int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew) {
+    if (!s || !Ynew) { set_error("null session or block"); return kFail; }
+    if (!bind_device()) return kFail;
+    return IMPL(s)->append_rows(Ynew);
+}
+int32_t trmf_session_rows(TrmfSession *s) { return s ? IMPL(s)->T : kFail; }
 
 int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val) {
     if (!s) return kFail;

@@ -1,152 +1,188 @@
-"""Model container, normalisation transform and forecasting helpers (pure NumPy, no GPU).
+"""The TRMF model object of the Python front end (host side, pure NumPy -- no GPU code here).
 
-Counterparts in the reference: NormalizedTransform python/trmf/trmf.py:82-96, Model :98-251.
+API contract (names, signatures, defaults, array layouts, RNG call order, file names), pinned by
+tests/test_python_frontend.py; the reference's counterpart is python/trmf/trmf.py:82-251:
+
+* ``Model``: ``W`` (T x k, C order), ``H`` (n x k, C order), ``lag_val`` (|L| x k, F order) wrapped as
+  ``PyMatrix`` views (``pyW``, ``pyH``, ``pylag_val``) that the C ABI updates in place; ``lag_set`` sorted uint32.
+* ``Model.initialize`` draws ``rand`` W, ``rand`` H, ``randn`` lag_val, in that order, after ``np.random.seed(seed)``;
+  a ``warm_start_model`` replaces them by the previous model rolled forward.
+* ``Model.save`` / ``Model.load``: ``arrays.npz`` (W, H, lag_val, lag_set) + ``other.pkl`` ({'transform': ...}).
+* ``NormalizedTransform``: per-series affine map ``y -> a*y + b`` to zero mean / unit variance.
 """
 import os
 import pickle
-from os import path
 
 import numpy as np
 import scipy.sparse as smat
 
 from .rf_util import PyMatrix
 
+_ARRAYS, _EXTRA = 'arrays.npz', 'other.pkl'
+
 
 class NormalizedTransform(object):
-    """Column-wise affine map to zero mean / unit variance (reference trmf.py:82-96)."""
+    """z-score per series: ``preprocess`` applies ``a*y + b`` with a = 1/std, b = -mean/std; ``postprocess`` undoes it.
+    Constant series (std = 0) keep a unit scale."""
 
     def __init__(self, Y):
-        Yd = Y.toarray() if smat.issparse(Y) else np.asarray(Y)
-        mean = np.asarray(Yd.mean(axis=0)).reshape(1, -1)
-        std = np.asarray(Yd.std(axis=0)).reshape(1, -1)
-        std[std == 0] = 1.0
-        self.a = 1. / std
-        self.b = -self.a * mean
+        dense = Y.toarray() if smat.issparse(Y) else np.asarray(Y)
+        center = dense.mean(axis=0, keepdims=True)
+        spread = dense.std(axis=0, keepdims=True)
+        spread = np.where(spread == 0, 1.0, spread)
+        self.a = 1.0 / spread
+        self.b = -self.a * center
+
+    def _check(self, Y):
+        assert Y.shape[1] == self.a.shape[1], 'series count differs from the fitted transform'
 
     def preprocess(self, Y):
-        assert Y.shape[1] == self.a.shape[1]
+        self._check(Y)
         return Y * self.a + self.b
 
     def postprocess(self, Y):
-        assert Y.shape[1] == self.a.shape[1]
+        self._check(Y)
         return (Y - self.b) / self.a
 
 
+def _sorted_lags(lag_set):
+    return np.array(sorted(lag_set), dtype=np.uint32)
+
+
+def _empty_factors(m, n, k, nlag, dtype):
+    """Zero-filled (W, H, lag_val) in the memory orders the C ABI requires (trmf.cpp:583-594)."""
+    return (np.zeros((m, k), dtype=dtype, order='C'), np.zeros((n, k), dtype=dtype, order='C'),
+            np.zeros((nlag, k), dtype=dtype, order='F'))
+
+
+def _ar_rollout(W, first, last, lag_set, lag_val):
+    """In place: W[i] = sum_l lag_val[l] * W[i - lag_set[l]] for i = first .. last-1, in time order."""
+    back = lag_set.astype(np.int64)
+    for i in range(first, last):
+        np.sum(W[i - back] * lag_val, axis=0, out=W[i])
+
+
 class Model(object):
-    """W (T x k, C order), H (n x k, C order), lag_val (|L| x k, F order), sorted uint32 lag_set."""
 
     def __init__(self, pyW=None, pyH=None, pylag_val=None, lag_set=None, transform=None):
-        self.pyW = pyW
-        self.pyH = pyH
-        self.pylag_val = pylag_val
+        self.pyW, self.pyH, self.pylag_val = pyW, pyH, pylag_val
         self.lag_set = lag_set
         self.transform = transform
 
-    k = property(lambda self: self.W.shape[1])
-    m = property(lambda self: self.W.shape[0])
-    n = property(lambda self: self.H.shape[0])
-    W = property(lambda self: self.pyW.py_buf['val'])
-    H = property(lambda self: self.pyH.py_buf['val'])
-    lag_val = property(lambda self: self.pylag_val.py_buf['val'])
-
-    # -- persistence: arrays.npz + other.pkl, same file names as the reference (trmf.py:131-168)
     @classmethod
-    def load(cls, path_to_folder, dtype=None):
-        assert path.isdir(path_to_folder)
-        with open(path.join(path_to_folder, 'other.pkl'), 'rb') as fh:
-            transform = pickle.load(fh)['transform']
-        with np.load(path.join(path_to_folder, 'arrays.npz')) as npz:
-            W, H, lag_val, lag_set = npz['W'], npz['H'], npz['lag_val'], npz['lag_set']
-        if dtype is None:
-            dtype = W.dtype
-        return cls(pyW=PyMatrix(np.ascontiguousarray(W), dtype), pyH=PyMatrix(np.ascontiguousarray(H), dtype),
-                   pylag_val=PyMatrix(np.asfortranarray(lag_val), dtype), lag_set=lag_set,
-                   transform=transform)
+    def from_arrays(cls, W, H, lag_val, lag_set, transform=None, dtype=None):
+        dtype = W.dtype if dtype is None else dtype
+        return cls(PyMatrix(np.ascontiguousarray(W), dtype), PyMatrix(np.ascontiguousarray(H), dtype),
+                   PyMatrix(np.asfortranarray(lag_val), dtype), lag_set=lag_set, transform=transform)
 
+    # the arrays the C side reads and writes are the ones pinned inside the PyMatrix views
+    @property
+    def W(self):
+        return self.pyW.py_buf['val']
+
+    @property
+    def H(self):
+        return self.pyH.py_buf['val']
+
+    @property
+    def lag_val(self):
+        return self.pylag_val.py_buf['val']
+
+    @property
+    def m(self):
+        return self.W.shape[0]
+
+    @property
+    def n(self):
+        return self.H.shape[0]
+
+    @property
+    def k(self):
+        return self.W.shape[1]
+
+    # ---- persistence ---------------------------------------------------------------------------
     def save(self, path_to_folder):
-        if not path.exists(path_to_folder):
-            os.makedirs(path_to_folder)
-        assert path.isdir(path_to_folder)
-        with open(path.join(path_to_folder, 'arrays.npz'), 'wb') as fh:
-            np.savez(fh, W=self.W, H=self.H, lag_val=self.lag_val, lag_set=self.lag_set)
-        with open(path.join(path_to_folder, 'other.pkl'), 'wb') as fh:
+        os.makedirs(path_to_folder, exist_ok=True)
+        np.savez(os.path.join(path_to_folder, _ARRAYS), W=self.W, H=self.H, lag_val=self.lag_val, lag_set=self.lag_set)
+        with open(os.path.join(path_to_folder, _EXTRA), 'wb') as fh:
             pickle.dump({'transform': self.transform}, fh)
 
-    # -- forecasting (trmf.py:170-193)
+    @classmethod
+    def load(cls, path_to_folder, dtype=None):
+        assert os.path.isdir(path_to_folder), path_to_folder
+        with np.load(os.path.join(path_to_folder, _ARRAYS)) as stored:
+            parts = {name: stored[name] for name in ('W', 'H', 'lag_val', 'lag_set')}
+        with open(os.path.join(path_to_folder, _EXTRA), 'rb') as fh:
+            extra = pickle.load(fh)
+        return cls.from_arrays(parts['W'], parts['H'], parts['lag_val'], parts['lag_set'],
+                               transform=extra['transform'], dtype=dtype)
+
+    # ---- forecasting -----------------------------------------------------------------------------
     def latent_forecast(self, window, Wnew=None):
+        """W extended by ``window`` timestamps through the AR model; the first ``m`` rows are W itself."""
+        total = self.m + window
         if Wnew is None:
-            Wnew = np.zeros((self.m + window, self.k), dtype=self.W.dtype, order='C')
-        else:
-            assert Wnew.shape == (self.m + window, self.k)
-            assert Wnew.dtype == self.W.dtype and Wnew.flags['C_CONTIGUOUS']
-        Wnew[:self.m, :] = self.W
-        lags = self.lag_set.astype(np.int64)
-        for i in range(self.m, self.m + window):
-            Wnew[i, :] = (Wnew[i - lags, :] * self.lag_val).sum(axis=0)
+            Wnew = np.zeros((total, self.k), dtype=self.W.dtype, order='C')
+        assert Wnew.shape == (total, self.k) and Wnew.dtype == self.W.dtype and Wnew.flags.c_contiguous
+        Wnew[:self.m] = self.W
+        _ar_rollout(Wnew, self.m, total, self.lag_set, self.lag_val)
         return Wnew
 
     def forecast(self, window, Ynew=None, threshold=None):
-        Wnew = self.latent_forecast(window)[self.m:, :]
+        """(Ynew, Wnew): the next ``window`` rows of Y and of W; values below ``threshold`` are clipped before the
+        transform (if any) is undone."""
+        Wnew = self.latent_forecast(window)[self.m:]
         if Ynew is None:
             Ynew = np.zeros((window, self.n), dtype=self.W.dtype, order='C')
         Ynew[:] = Wnew.dot(self.H.T)
         if threshold is not None:
-            Ynew[Ynew < threshold] = threshold
+            np.maximum(Ynew, threshold, out=Ynew)
         if self.transform is not None:
             Ynew[:] = self.transform.postprocess(Ynew)
         return Ynew, Wnew
 
-    # -- synthetic data (trmf.py:195-220)
+    # ---- construction ------------------------------------------------------------------------------
     @staticmethod
     def syn_gen(m, n, k, lag_set, seed=None, noise=0.01, dtype=np.float32):
+        """A low-rank matrix whose temporal factor follows an AR model over ``lag_set``.  Random draws in this order:
+        W, H, lag_val (standard normal), then the innovation noise of rows midx.. of W."""
         if seed is not None:
             np.random.seed(seed)
-        lag_set = np.array(sorted(lag_set), dtype=np.uint32)
-        midx = int(lag_set.max())
-        W = np.zeros((m, k), dtype=dtype, order='C')
-        H = np.zeros((n, k), dtype=dtype, order='C')
-        lag_val = np.zeros((len(lag_set), k), dtype=dtype, order='F')
-        W[:] = np.random.randn(m, k)
-        H[:] = np.random.randn(n, k)
-        lag_val[:] = np.random.randn(len(lag_set), k)
-        lag_val = lag_val.dot(np.diag(1. / (np.absolute(lag_val).sum(axis=0) + 0.1)))
-        lags = lag_set.astype(np.int64)
-        for i in range(midx, m):
-            W[i, :] = (W[i - lags, :] * lag_val).sum(axis=0)
-        W[midx:, :] += noise * np.random.randn(m - midx, k)
+        lags = _sorted_lags(lag_set)
+        W, H, theta = _empty_factors(m, n, k, len(lags), dtype)
+        for target in (W, H, theta):
+            target[:] = np.random.randn(*target.shape)
+        theta = theta.dot(np.diag(1.0 / (np.abs(theta).sum(axis=0) + 0.1)))      # contractive columns
+        start = int(lags.max())
+        _ar_rollout(W, start, m, lags, theta)
+        W[start:] += noise * np.random.randn(m - start, k)
         Y = np.zeros((m, n), dtype=dtype, order='C')
         Y[:] = W.dot(H.T)
-        return {'W': W, 'H': H, 'lag_val': lag_val, 'lag_set': lag_set, 'Y': Y, 'k': k}
+        return {'W': W, 'H': H, 'lag_val': theta, 'lag_set': lags, 'Y': Y, 'k': k}
 
-    # -- random start / warm start (trmf.py:222-251)
     @classmethod
     def initialize(cls, Y, lag_set, k, warm_start_model=None, seed=None, dtype=None, transform=None):
         if seed is not None:
             np.random.seed(seed)
-        if dtype is None:
-            dtype = Y.dtype
+        dtype = Y.dtype if dtype is None else dtype
         m, n = Y.shape
-        lag_set = np.array(sorted(lag_set), dtype=np.uint32)
-        W = np.zeros((m, k), dtype=dtype, order='C')
-        H = np.zeros((n, k), dtype=dtype, order='C')
-        lag_val = np.zeros((len(lag_set), k), dtype=dtype, order='F')
+        lags = _sorted_lags(lag_set)
+        W, H, theta = _empty_factors(m, n, k, len(lags), dtype)
         W[:] = np.random.rand(m, k)
         H[:] = np.random.rand(n, k)
-        lag_val[:] = np.random.randn(len(lag_set), k)
-        if warm_start_model is not None:
-            prev = warm_start_model
-            assert prev.k == k and prev.n == n and prev.m <= m
-            assert len(lag_set) == len(prev.lag_set)
+        theta[:] = np.random.randn(len(lags), k)
+        prev = warm_start_model
+        if prev is not None:
+            assert (prev.k, prev.n) == (k, n) and prev.m <= m and len(prev.lag_set) == len(lags)
             W[:] = prev.latent_forecast(m - prev.m)
             H[:] = prev.H
-            lag_val[:] = prev.lag_val
+            theta[:] = prev.lag_val
             transform = prev.transform
-        if transform is not None:          # any truthy/non-None request -> fit a fresh transform on Y
+        if transform is not None:                       # any request for a transform: fit a fresh one on this Y
             transform = NormalizedTransform(Y)
-        return cls(pyW=PyMatrix(W, dtype), pyH=PyMatrix(H, dtype), pylag_val=PyMatrix(lag_val, dtype),
-                   lag_set=lag_set, transform=transform)
+        return cls(PyMatrix(W, dtype), PyMatrix(H, dtype), PyMatrix(theta, dtype), lag_set=lags, transform=transform)
 
     def fit(self, Y, **kw):
-        """Convenience: ``model.fit(Y, ...)`` == ``train(Y, model, ...)``."""
+        """``model.fit(Y, ...)`` is ``train(Y, model, ...)``."""
         from .trmf import train
         return train(Y, self, **kw)

@@ -44,6 +44,8 @@ def bind(lib):
     lib.trmf_session_run.argtypes = [c_void_p, c_int32]; lib.trmf_session_run.restype = c_int32
     lib.trmf_session_log_norms.argtypes = [c_void_p, c_int32]; lib.trmf_session_log_norms.restype = c_int32
     lib.trmf_session_sync.argtypes = [c_void_p]; lib.trmf_session_sync.restype = c_int32
+    lib.trmf_session_append_rows.argtypes = [c_void_p, P]; lib.trmf_session_append_rows.restype = c_int32
+    lib.trmf_session_rows.argtypes = [c_void_p]; lib.trmf_session_rows.restype = c_int32
     lib.trmf_session_download.argtypes = [c_void_p, P, P, P]; lib.trmf_session_download.restype = c_int32
     lib.trmf_session_stats.argtypes = [c_void_p, POINTER(TrmfIterStats), c_int32]
     lib.trmf_session_stats.restype = c_int32
@@ -96,6 +98,17 @@ class Session(object):
     def sync(self):
         self._check(self.lib.trmf_session_sync(self.handle), 'trmf_session_sync')
         return self
+
+    def append_rows(self, Ynew):
+        """Append the timestamps of ``Ynew`` (Tn x n, same storage class as the session's Y) to the resident problem;
+        W is extended on the device by the AR recursion, H and the lag weights are kept.  ``self.model`` must be
+        replaced by a model with ``rows()`` timestamps before the next ``download()``."""
+        block = Ynew if isinstance(Ynew, PyMatrix) else PyMatrix(Ynew, dtype=self.model.W.dtype)
+        self._check(self.lib.trmf_session_append_rows(self.handle, byref(block)), 'trmf_session_append_rows')
+        return self
+
+    def rows(self):
+        return self._check(self.lib.trmf_session_rows(self.handle), 'trmf_session_rows')
 
     def download(self):
         m = self.model

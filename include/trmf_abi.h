@@ -127,6 +127,17 @@ TRMF_API int32_t trmf_session_run(TrmfSession *s, int32_t iters);
  * reference evaluates these norms only under `verbose` (trmf.cpp:659-688); with the switch off the
  * fields read -1 and an iteration is about 30 us shorter.  c_trmf_train follows `verbose`.        */
 TRMF_API int32_t trmf_session_log_norms(TrmfSession *s, int32_t on);
+/* Append Ynew (Tn x n, NEW timestamps, same storage class -- sparse or dense -- as the session's Y) to the resident
+ * problem: the rolling-window caller of the reference (python/trmf/trmf.py:303-329) retrains on a prefix that
+ * grows by one window and warm-starts from the previous model (trmf.py:237-246).  Only the block (and, for a
+ * sparse Y, one 4-byte pointer per item) is uploaded: CSR rows are appended, the CSC is rebuilt on the device,
+ * a dense Y's second orientation is re-strided on the device, W gains Tn rows by the AR recursion with the
+ * current lag weights (Model.latent_forecast, trmf.py:170-181); H and lag_val are kept.  The iteration counter
+ * restarts at 1 like a fresh c_trmf_train call (period_* gating, trmf.cpp:647).  Blocking.  With a communicator
+ * active every rank must call it with the same block. */
+TRMF_API int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew);
+/* Number of timestamps currently held by the session (rows of W). */
+TRMF_API int32_t trmf_session_rows(TrmfSession *s);
 /* Block until all enqueued work of the session has finished. */
 TRMF_API int32_t trmf_session_sync(TrmfSession *s);
 /* Copy the current factors back into caller PyMatrix views (same shapes as at create). */

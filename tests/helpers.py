@@ -9,7 +9,9 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 
 def golden_names():
-    return sorted(os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+    # solver cases only; py_*.npz hold the Python-harness captures (tests/golden/make_py_golden.py)
+    return sorted(name for name in (os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+                  if not name.startswith('py_'))
 
 
 def load_golden(name):
