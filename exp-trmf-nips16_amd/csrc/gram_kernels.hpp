@@ -414,36 +414,65 @@ template <int NT> __device__ __forceinline__ constexpr int quad_slab_col_offset(
     return n;
 }
 
-// Four right-looking Cholesky factorisations side by side (one per 16-lane row), forward substitution
-// fused, then the row-oriented back substitution.  areg[q][s] = A[s][16q+c] (+lambda on the diagonal,
-// unit diagonal on pad rows so that no k-guard is needed), bz[q] = b[16q+c]; returns x[q] = x[16q+c].
-template <int NT, int KMAX, int ABL = 0>
-__device__ __forceinline__ void quad_factor_solve(float (&areg)[NT][KMAX], float (&bz)[NT], float (&x)[NT], int c) {
+// Four right-looking Cholesky factorisations side by side (one per 16-lane row), then the row-oriented back
+// substitution.  a4[q][R][i] = A[4R+i][16q+c] (+lambda on the diagonal, unit diagonal on pad rows so that no
+// k-guard is needed); returns x[q] = x[16q+c].
+//
+// Step j scales row j (u = A[j][.] / sqrt(A[j][j]), zero left of and on the diagonal) and removes its outer
+// product from the rows below.  That rank-1 update runs on the matrix pipe, four rows at a time:
+// v_mfma_f32_4x4x1_16b_f32 is 16 independent 4x4 outer products -- block = 4 neighbouring lanes, result VGPR i
+// of lane 4b+jj = C + A[lane 4b+i] * B[lane 4b+jj] -- which in this layout (lane = column, VGPR = row) is exactly
+//     A[4R+i][16q+c] -= u[4R+i] * u[16q+c]      for i = 0..3, all 16 columns c of block q, all four systems,
+// with the B operand the lane's own u[q] and the A operand one ds_swizzle (the quad holding u[4R..4R+3]
+// replicated to every quad of the 16-lane row).  One swizzle + (NT - q(R)) MFMAs per row quad replace four
+// swizzles + 4 (NT - q) FMAs, and an MFMA issues 512 flops in 8 cycles where four v_fma_f32 take 16
+// (scripts/ubench/mfma4x4.hip); the product is rounded once like fmaf, so the arithmetic is unchanged.
+// Rows <= j inside the first quad see u = 0 and stay as they are.
+//
+// RHS_IN: the right-hand side sits in column KP-1 of the matrix (the pad column the Gram MFMAs accumulated
+// sum(y x) into, gram_ring RHS_PAD).  The forward substitution then needs no code at all -- column KP-1 is
+// scaled and updated like every other column, and afterwards holds z = U^-T b -- and the back substitution
+// treats it as one more unknown fixed at -1:  x_j = -(sum_{t>j} U[j][t] x_t) / U[j][j]  with  x_{KP-1} = -1.
+typedef float quad_f4 __attribute__((ext_vector_type(4)));
+
+// value of the quad Q (lanes 4Q..4Q+3) of the caller's 16-lane row, replicated to all four quads of that row
+template <int Q> __device__ __forceinline__ float row_quad_bcast(float v) {
+    constexpr int pattern = ((Q << 2) << 5) | 0x13;      // and_mask = 0b10011, or_mask = 4Q, xor_mask = 0
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), pattern));
+}
+
+template <int NT, int KMAX, bool RHS_IN, int ABL = 0>
+__device__ __forceinline__ void quad_factor_solve(quad_f4 (&a4)[NT][KMAX / 4], float (&bz)[NT], float (&x)[NT], int c) {
+    constexpr int NR = KMAX / 4;                         // row quads
     float dinv[NT];
 #pragma unroll
     for (int q = 0; q < NT; q++) dinv[q] = 0;
     if constexpr (!(ABL & 2))
     static_for<KMAX>([&](auto J) {
-        constexpr int j = decltype(J)::value, qj = j >> 4, cj = j & 15;
+        constexpr int j = decltype(J)::value, qj = j >> 4, cj = j & 15, Rj = j >> 2, ij = j & 3;
         {   // one straight-line block: the scheduler can software-pipeline across steps
-            const float inv = inv_sqrt(row_bcast<cj>(areg[qj][j]));
-            float u[NT];
+            const float inv = __builtin_amdgcn_rsqf(row_bcast<cj>(a4[qj][Rj][ij]));
+            float u[NT], nu[NT];
 #pragma unroll
             for (int q = qj; q < NT; q++) {
-                u[q] = areg[q][j] * inv;
+                u[q] = a4[q][Rj][ij] * inv;
                 if (q == qj && c <= cj) u[q] = 0;       // row j of U, strictly right of the diagonal
-                areg[q][j] = u[q];
+                a4[q][Rj][ij] = u[q];
+                nu[q] = -u[q];
             }
-            const float zj = row_bcast<cj>(bz[qj]) * inv;
+            if constexpr (!RHS_IN) {
+                const float zj = row_bcast<cj>(bz[qj]) * inv;
 #pragma unroll
-            for (int q = qj; q < NT; q++) bz[q] = fmaf(-u[q], zj, bz[q]);
-            if (c == cj) { bz[qj] = zj; dinv[qj] = inv; }
-            static_for<KMAX>([&](auto Sx) {
-                constexpr int s = decltype(Sx)::value, qs = s >> 4, cs = s & 15;
-                if constexpr (s > j) {
-                    const float us = row_bcast<cs>(u[qs]);
+                for (int q = qj; q < NT; q++) bz[q] = fmaf(-u[q], zj, bz[q]);
+                if (c == cj) bz[qj] = zj;
+            }
+            if (c == cj) dinv[qj] = inv;
+            static_for<NR>([&](auto Rx) {
+                constexpr int R = decltype(Rx)::value, qs = (4 * R) >> 4;
+                if constexpr (4 * R + 3 > j) {
+                    const float nus = row_quad_bcast<R & 3>(nu[qs]);     // -u[4R + (lane & 3)]
 #pragma unroll
-                    for (int q = qs; q < NT; q++) areg[q][s] = fmaf(-us, u[q], areg[q][s]);
+                    for (int q = qs; q < NT; q++) a4[q][R] = __builtin_amdgcn_mfma_f32_4x4x1f32(nus, u[q], a4[q][R], 0, 0, 0);
                 }
             });
         }
@@ -451,13 +480,18 @@ __device__ __forceinline__ void quad_factor_solve(float (&areg)[NT][KMAX], float
     // back substitution U x = z, row-oriented, reduction inside the 16-lane row (DPP)
 #pragma unroll
     for (int q = 0; q < NT; q++) x[q] = 0;
+    if constexpr (RHS_IN) {
+        if (c == 15) x[NT - 1] = -1.0f;                 // the rhs column as an unknown fixed at -1
+#pragma unroll
+        for (int q = 0; q < NT; q++) bz[q] = 0;
+    }
     if constexpr (!(ABL & 4))
     static_for<KMAX>([&](auto Jr) {
-        constexpr int j = KMAX - 1 - decltype(Jr)::value, qj = j >> 4, cj = j & 15;
+        constexpr int j = KMAX - 1 - decltype(Jr)::value, qj = j >> 4, cj = j & 15, Rj = j >> 2, ij = j & 3;
         {
             float part = 0;
 #pragma unroll
-            for (int q = qj; q < NT; q++) part = fmaf(areg[q][j], x[q], part);
+            for (int q = qj; q < NT; q++) part = fmaf(a4[q][Rj][ij], x[q], part);
             const float sum = row16_allsum_dpp(part);
             const float xv = (bz[qj] - sum) * dinv[qj];
             if (c == cj) x[qj] = xv;
@@ -513,14 +547,14 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
     float *S = lds_slab[wave];
     typedef float f4 __attribute__((ext_vector_type(4)));
 
-    // areg[q][s] = A[s][16q + c] of this lane row's system; only s <= 16q+15 is ever touched
-    float areg[NT][KMAX];
+    // a4[q][R][i] = A[4R+i][16q + c] of this lane row's system; only rows <= 16q+15 are ever touched
+    quad_f4 a4[NT][KMAX / 4];
     float bz[NT];
 #pragma unroll
     for (int q = 0; q < NT; q++) {
         bz[q] = 0;
 #pragma unroll
-        for (int s = 0; s < KMAX; s++) areg[q][s] = (s == kTile * q + c) ? 1.0f : 0.0f;   // idle rows: identity
+        for (int s = 0; s < KMAX; s++) a4[q][s >> 2][s & 3] = (s == kTile * q + c) ? 1.0f : 0.0f;   // idle rows: identity
     }
     bool mine = false;
 
@@ -537,9 +571,9 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
     st.clear();
     // system `sys` is complete in st: + lambda on the diagonal (trmf.cpp:393), accumulators -> slab
     // (4 consecutive rows per store), then lane row `sys` pulls its columns into registers
-    // rhs in the pad columns of the panel (quad_inject) when the rank leaves >= 8 pad columns: b_s = A[s][KP-1]
+    // rhs in the pad columns of the panel (quad_inject) when the rank leaves >= 8 pad columns: b_s = A[s][KP-1],
+    // which the factorisation then carries along as an ordinary column (quad_factor_solve, RHS_IN)
     constexpr bool PAD = KMAX <= kTile * NT - 8;
-    constexpr int kBcol = quad_slab_col_offset<NT>(NT - 1) + 15 * (kTile * NT + 4);      // slab column KP-1
     auto finalize = [&](int sys) {
         if constexpr (!PAD) {
 #pragma unroll
@@ -567,14 +601,11 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
             mine = true;
 #pragma unroll
             for (int q = 0; q < NT; q++) {
-                bz[q] = PAD ? S[kBcol + kTile * q + c] : st.b[q];
+                if constexpr (!PAD) bz[q] = st.b[q];
 #pragma unroll
                 for (int s4 = 0; s4 < KMAX / 4; s4++) {
-                    if (4 * s4 <= kTile * q + 15) {
-                        const f4 v = *reinterpret_cast<const f4 *>(&S[quad_slab_col_offset<NT>(q) + c * (kTile * (q + 1) + 4) + 4 * s4]);
-                        areg[q][4 * s4 + 0] = v[0]; areg[q][4 * s4 + 1] = v[1];
-                        areg[q][4 * s4 + 2] = v[2]; areg[q][4 * s4 + 3] = v[3];
-                    }
+                    if (4 * s4 <= kTile * q + 15)
+                        a4[q][s4] = *reinterpret_cast<const f4 *>(&S[quad_slab_col_offset<NT>(q) + c * (kTile * (q + 1) + 4) + 4 * s4]);
                 }
             }
         }
@@ -592,7 +623,7 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
     }
 
     float x[NT];
-    quad_factor_solve<NT, KMAX, ABL>(areg, bz, x, c);
+    quad_factor_solve<NT, KMAX, PAD, ABL>(a4, bz, x, c);
     if (mine) {     // logical columns {c, 16+c, ...} are adjacent in the interleaved layout: one vector store
         RealVec<NT> o;
 #pragma unroll

@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void csc_append_kernel(const uint32_t *__restr
 __global__ __launch_bounds__(64) void latent_forecast_kernel(real *__restrict__ W, int T0, int T1, int KP, int NT, int k,
                                                              const uint32_t *__restrict__ lag_set, int nlag,
                                                              const real *__restrict__ theta) {
+#pragma clang fp contract(off)      // product and sum are rounded separately, like the NumPy expression (hipcc contracts by default)
     const int t = threadIdx.x;
     if (t >= k) return;
     const int tp = colpos(t, NT);
@@ -53,9 +54,8 @@ __global__ __launch_bounds__(64) void latent_forecast_kernel(real *__restrict__ 
         for (int l = 0; l < nlag; l++) {
             const int src = i - (int)lag_set[l];
             const real w = src >= 0 ? W[(size_t)src * KP + tp] : real(0);
-            real prod;
-            if constexpr (sizeof(real) == 4) { prod = __fmul_rn(w, theta[(size_t)t * nlag + l]); acc = __fadd_rn(acc, prod); }
-            else { prod = __dmul_rn(w, theta[(size_t)t * nlag + l]); acc = __dadd_rn(acc, prod); }
+            const real prod = w * theta[(size_t)t * nlag + l];
+            acc = acc + prod;
         }
         W[(size_t)i * KP + tp] = acc;
     }
