@@ -142,6 +142,7 @@ struct TrmfSessionImpl {
         if (const char *e = getenv("TRMF_FSOLVE")) {
             const std::string m(e);
             use_quad = use_quad && m != "wave";
+            use_grid = use_grid && m != "wave";
         }
         if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -354,6 +355,15 @@ struct TrmfSessionImpl {
                            Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
         return 0;
     }
+    template <int NT_, int KMAX_> int launch_fsolve_grid(uint32_t rb, uint32_t re) {
+        const uint32_t rows = re - rb;
+        if (rows == 0) return 0;
+#if !defined(TRMF_F32)
+        hipLaunchKernelGGL((fsolve_grid_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
+                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
+#endif
+        return 0;
+    }
     template <int NT_, int KMAX_> int launch_fsolve_quad(uint32_t rb, uint32_t re) {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
@@ -379,8 +389,9 @@ struct TrmfSessionImpl {
 #endif
         return 0;
     }
-    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64 or TRMF_FSOLVE=wave: one system per wavefront
-    bool use_quad = sizeof(real) == 4;
+    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64: one system per wavefront, block-cyclic over an
+    // 8 x 8 lane grid (fsolve_grid_kernel); TRMF_FSOLVE=wave: one system per wavefront, one column per lane
+    bool use_quad = sizeof(real) == 4, use_grid = sizeof(real) == 8;
     // X-side Gram build across ranks: sharded rows + all-gather of G (64 MB at config 3) pays only when a
     // rank's share of the gather is cheaper than the rows it no longer computes -- true on 8 GPUs, not on 2.
     // First call measures (kernel and gather time of every rank, exchanged through the communicator so that
@@ -403,6 +414,18 @@ struct TrmfSessionImpl {
                 case 48: launch_fsolve_quad<3, 48>(rb, re); break;
                 case 56: launch_fsolve_quad<4, 56>(rb, re); break;
                 case 64: launch_fsolve_quad<4, 64>(rb, re); break;
+                default: set_error("unsupported rank"); return kFail;
+            }
+        } else if (use_grid) {
+            switch (KMAX) {
+                case 8:  launch_fsolve_grid<1, 8>(rb, re); break;
+                case 16: launch_fsolve_grid<1, 16>(rb, re); break;
+                case 24: launch_fsolve_grid<2, 24>(rb, re); break;
+                case 32: launch_fsolve_grid<2, 32>(rb, re); break;
+                case 40: launch_fsolve_grid<3, 40>(rb, re); break;
+                case 48: launch_fsolve_grid<3, 48>(rb, re); break;
+                case 56: launch_fsolve_grid<4, 56>(rb, re); break;
+                case 64: launch_fsolve_grid<4, 64>(rb, re); break;
                 default: set_error("unsupported rank"); return kFail;
             }
         } else
