@@ -181,6 +181,9 @@ __global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XStat
 }
 
 // ---- out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b) ; partial of <dotwith, out> ----------------------
+// Multi-GPU (TrmfSessionImpl::cg_shard): every rank evaluates its own block of timestamps -- the k x k Gram per
+// timestamp is the only HBM-sized stream of a CG step, and the Hessian is block-diagonal there (trmf.cpp:269-288)
+// -- and the blocks of `out` and of the partial sums are all-gathered; everything else of the CG stays replicated.
 // grad (trmf.cpp:99-123 + 247-267) when minus_b, Hessian-vector product (trmf.cpp:125-149 + 269-288)
 // otherwise.  One thread per (row, column); `rpb` rows per block; the row's v is staged in LDS.
 // dot_mode 0: <out,out>   1: <v,out>
@@ -193,7 +196,8 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
                                                     const real *__restrict__ G,
                                                     const real *__restrict__ Bv, int minus_b,
                                                     real *__restrict__ out, int dot_mode,
-                                                    double *__restrict__ Pdot, int rpb) {
+                                                    double *__restrict__ Pdot, int rpb,
+                                                    int row0, int nrows, int slot0) {
     __shared__ double smem[256];
     __shared__ real vs[256];
     if (Prr_cur != nullptr) {
@@ -205,10 +209,12 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     const int tp = colpos(t, p.NT);                                 // its position in a vector row
     const bool active_lane = lr < rpb;
     double dot = 0, lq = 0;
-    const int ngroups = (p.T + rpb - 1) / rpb;
+    // rows [row0, row0 + nrows): all of them, or this rank's block when the Gram product is sharded across GPUs
+    // (the partial sums then land in this rank's slot range [slot0, slot0 + gridDim.x) and are all-gathered)
+    const int ngroups = (nrows + rpb - 1) / rpb;
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int i = grp * rpb + lr;
-        const bool active = active_lane && i < p.T;
+        const int i = row0 + grp * rpb + lr;
+        const bool active = active_lane && grp * rpb + lr < nrows;
         real x = 0;
         if (active) x = v[(size_t)i * KP + tp];
         __syncthreads();
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     }
     dot = block_allsum(dot, smem);
     lq = block_allsum(lq, smem);
-    if (threadIdx.x == 0) { Pdot[blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + blockIdx.x] = lq; }
+    if (threadIdx.x == 0) { Pdot[slot0 + blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + slot0 + blockIdx.x] = lq; }
 }
 
 // ---- fused Hessian-vector / gradient kernel, tiled over time in LDS --------------------------------

@@ -27,6 +27,9 @@ struct Comm {
     virtual ~Comm() {}
     // Gather in place: rank r owns bytes [off[r], off[r+1]) of dbuf (device memory).
     virtual int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) = 0;
+    // Several gathers issued between group_begin() and group_end() may be fused into one transfer round.
+    virtual int group_begin() { return 0; }
+    virtual int group_end() { return 0; }
 };
 
 struct SelfComm : Comm {
@@ -97,6 +100,12 @@ struct RcclComm : Comm {
     RcclApi::CommT comm = nullptr;
     RcclComm() { call_when_single = true; }   // keeps the RCCL call path testable on a 1-GPU box
     ~RcclComm() override { if (comm) rccl_api().CommDestroy(comm); }
+    int group_begin() override { return rccl_api().GroupStart() == 0 ? 0 : kFail; }
+    int group_end() override {
+        const int rc = rccl_api().GroupEnd();
+        if (rc != 0) { set_error(std::string("RCCL group failed: ") + rccl_api().GetErrorString(rc)); return kFail; }
+        return 0;
+    }
     int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) override {
         RcclApi &api = rccl_api();
         constexpr int kNcclInt8 = 0;                     // ncclInt8 / ncclChar

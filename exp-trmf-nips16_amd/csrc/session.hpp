@@ -263,6 +263,7 @@ struct TrmfSessionImpl {
                 xbounds[r] = (uint64_t)T * r / comm->world;
             }
         }
+        decide_cg_shard();
         return 0;
     }
 
@@ -462,9 +463,9 @@ struct TrmfSessionImpl {
                                Yr_val.p, H.p, Wv, lossrow.p, rb, re, (uint32_t)n);
     }
     int gram_x() {
-        if (gramx_mode == kGramxMeasure && gramx_calls == 1 && gramx_decide()) return kFail;
-        const bool replicate = gramx_mode == kGramxReplicate;
-        const bool measure = gramx_mode == kGramxMeasure;
+        if (!cg_shard && gramx_mode == kGramxMeasure && gramx_calls == 1 && gramx_decide()) return kFail;
+        const bool replicate = gramx_mode == kGramxReplicate && !cg_shard;
+        const bool measure = gramx_mode == kGramxMeasure && !cg_shard;
         const uint32_t rb = replicate ? 0u : (uint32_t)xbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)T : (uint32_t)xbounds[comm->rank + 1];
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx0, stream));
@@ -477,6 +478,7 @@ struct TrmfSessionImpl {
         TRMF_HIP_CHECK(hipGetLastError());
         gramx_calls++;
         if (replicate) return 0;                                    // every rank built every row: nothing to gather
+        if (cg_shard) return 0;                                     // sharded Gram product: a rank only ever reads its own G / b rows
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx1, stream));
         if (gather_rows(G.p, xbounds, (size_t)k * k * sizeof(real))) return kFail;
         if (gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
@@ -610,6 +612,22 @@ struct TrmfSessionImpl {
         }
 #undef TRMF_LAUNCH_HV_KQ
     }
+    // Multi-GPU, unfused path: shard the cached-Gram product of every CG step.  It pays when the
+    // rows a rank no longer streams (T k^2 s (1 - 1/N) bytes at ~4 TB/s) outweigh an all-gather of T KP s bytes per
+    // step (latency ~40 us + bytes over the rank's xGMI links); the fused one-launch-per-step path is faster
+    // replicated at the sizes it covers.  TRMF_CG=shard|replicate overrides.
+    bool cg_shard = false;
+    int apply_slots = 1;         // partial-sum slots (= workgroups of apply_kernel) per rank when sharded
+    void decide_cg_shard() {
+        cg_shard = false;
+        apply_slots = std::max(1, std::min(nba, kMaxPartials / std::max(1, comm->world)));
+        if (comm->world <= 1 || tile_TI > 0 || full) return;
+        const double N = comm->world, sz = sizeof(real);
+        const double t_saved = (double)T * k * k * sz * (1.0 - 1.0 / N) / 4e12;
+        const double t_gather = 40e-6 + (double)T * KP * sz * (1.0 - 1.0 / N) / ((N - 1.0) * 50e9);
+        cg_shard = t_saved > 2.0 * t_gather;
+        if (const char *e = getenv("TRMF_CG")) cg_shard = (e[0] == 's');
+    }
     // Unfused path (long lag sets): out = H*v (or the gradient when minus_b) as ar_residual + apply.
     // `fuse`: v is the previous direction and the new one is formed on the fly.
     int hv(const real *v, bool fuse, const real *rvec, real *dnew, const double *Pcur, const double *Pprev,
@@ -622,9 +640,26 @@ struct TrmfSessionImpl {
         else
             hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
                                v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
-        hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
-                           lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb);
-        return 0;
+        if (!cg_shard) {
+            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
+                               lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, 0, T, 0);
+            return 0;
+        }
+        // Gram product on this rank's timestamps only; its rows of `out` and its slots of the partial sums are
+        // all-gathered (one grouped round), so every rank continues with identical vectors and scalars
+        const int rb = (int)xbounds[comm->rank], re = (int)xbounds[comm->rank + 1];
+        hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
+                           lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, rb, re - rb,
+                           comm->rank * apply_slots);
+        TRMF_HIP_CHECK(hipGetLastError());
+        std::vector<uint64_t> poff(comm->world + 1);
+        for (int r = 0; r <= comm->world; r++) poff[r] = (uint64_t)r * apply_slots * sizeof(double);
+        if (comm->group_begin()) return kFail;
+        int rc = gather_rows(out, xbounds, (size_t)KP * sizeof(real));
+        if (rc == 0) rc = comm->allgatherv(P(P_DOT), poff.data(), stream);
+        if (rc == 0 && minus_b) rc = comm->allgatherv(P(P_LQ), poff.data(), stream);
+        if (comm->group_end()) return kFail;
+        return rc;
     }
     const real *Gmat() const { return full ? GSx.p : G.p; }      // shared H^T H or the per-timestamp cache
 
@@ -660,25 +695,26 @@ struct TrmfSessionImpl {
             TRMF_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0);           // gradient, <g,g>, AR/ridge sums
-        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, g.p,
+        if (hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0)) return kFail;   // gradient, <g,g>, AR/ridge sums
+        const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
+        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, ndot, g.p,
                            s.p, r.p, d0.p);
         real *dcur = d0.p, *dalt = d1.p;
         for (int it = 0; it < maxcg; it++) {
             double *Pcur = P(P_RR0 + (it & 1)), *Pnext = P(P_RR0 + ((it + 1) & 1));
             if (it == 0) {
-                hv(dcur, false, nullptr, nullptr, Pcur, nullptr, 0, Hd.p, 1);
+                if (hv(dcur, false, nullptr, nullptr, Pcur, nullptr, 0, Hd.p, 1)) return kFail;
             } else {
-                hv(dcur, true, r.p, dalt, Pcur, Pnext /* = rho[it-1] */, 0, Hd.p, 1);
+                if (hv(dcur, true, r.p, dalt, Pcur, Pnext /* = rho[it-1] */, 0, Hd.p, 1)) return kFail;
                 std::swap(dcur, dalt);
             }
             hipLaunchKernelGGL(cg_update_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pnext, P(P_DOT),
-                               nbe, nba, it, dcur, Hd.p, s.p, r.p);
+                               nbe, ndot, it, dcur, Hd.p, s.p, r.p);
         }
         double *Pfinal = P(P_RR0 + (maxcg & 1));
         hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, r.p, r.p, w_new.p, Pb);
-        hv(s.p, false, nullptr, nullptr, nullptr, nullptr, 0, Hd.p, 1);          // H s, <s,Hs>
-        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nba, Pfinal, w_new.p,
+        if (hv(s.p, false, nullptr, nullptr, nullptr, nullptr, 0, Hd.p, 1)) return kFail;  // H s, <s,Hs>
+        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, ndot, Pfinal, w_new.p,
                            W.p, log_x, log_n);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;

@@ -10,10 +10,17 @@ for p in (os.path.join(ROOT, 'exp-trmf-nips16_amd'), os.path.join(ROOT, 'oracle'
         sys.path.insert(0, p)
 
 
-def _problem():
+SHAPES = {
+    'small': dict(n=900, T=400, k=12, nlag=4, density=0.06),
+    'c4': dict(n=3000, T=1200, k=40, nlag=16, density=0.04),       # BASELINE config 4's rank and lag set, scaled down
+}
+
+
+def _problem(shape='small'):
     from trmf import synth
-    p = synth.sparse_problem(n=900, T=400, k=12, nlag=4, density=0.06, dtype=np.float64, seed=21)
-    m = synth.initial_model(p['Y'], p['lag_set'], 12, seed=21)
+    c = SHAPES[shape]
+    p = synth.sparse_problem(n=c['n'], T=c['T'], k=c['k'], nlag=c['nlag'], density=c['density'], dtype=np.float64, seed=21)
+    m = synth.initial_model(p['Y'], p['lag_set'], c['k'], seed=21)
     return p, m
 
 
@@ -53,16 +60,18 @@ def cpu_sharded_fsolve(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def gpu_host_staged(rank, world, port, out, iters):
+def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None):
     """Two processes on ONE GPU, host-staged all-gather over gloo: the sharded device path must give
-    results bit-identical across ranks and equal to the single-process run."""
+    results bit-identical across ranks and equal to the single-process run.  `env`: switches of the library
+    (e.g. TRMF_NO_HV_TILE / TRMF_CG to run the sharded Gram product of the unfused CG)."""
     import torch.distributed as dist
+    os.environ.update(env or {})
     from trmf import dist as tdist, session, synth
     from helpers import make_model
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
     res = {}
     for dtype in (np.float32, np.float64):
-        p, m0 = _problem()
+        p, m0 = _problem(shape)
         Y = p['Y'].astype(dtype)
         W0, H0, T0 = m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype))
         tdist.init_host_staged(dtype)

@@ -27,7 +27,7 @@ def _spawn(fn, world, *args):
     procs = [ctx.Process(target=fn, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=300) for _ in range(1 if fn.__name__ == 'cpu_sharded_fsolve' else world)]
+    out = [q.get(timeout=600) for _ in range(1 if fn.__name__ == 'cpu_sharded_fsolve' else world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -59,6 +59,51 @@ def test_two_ranks_one_gpu_match_single_process():
             # every kernel is deterministic and the CG runs replicated: bit-identical everywhere
             assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val)
             assert cg == [x['cg_iter'] for x in st]
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_config4_shape_replicated_cg():
+    """BASELINE config 4's rank and lag set (k=40, |L|=16; sizes scaled to a one-GPU test): F rows and X-Gram rows
+    sharded over two ranks, fused CG replicated -- bit-identical to the single-process run, in both precisions."""
+    import dist_worker
+    from trmf import session, synth
+    iters = 3
+    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters, 'c4'))
+    p, m0 = dist_worker._problem('c4')
+    for dtype in (np.float32, np.float64):
+        name = np.dtype(dtype).name
+        model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
+        with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
+            s.run(iters); st = s.stats(iters); s.download()
+        for r in (0, 1):
+            W, H, Th, cg = out[r][name]
+            assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val)
+            assert cg == [x['cg_iter'] for x in st]
+
+
+@pytest.mark.gpu
+def test_two_ranks_one_gpu_sharded_cg_gram_product(monkeypatch):
+    """The sharded form of the CG (unfused path: every rank multiplies its own timestamps' cached Grams, the rows of
+    H d and the partial sums are all-gathered each step): both ranks bit-identical to each other, and
+    equal to the single-process unfused run up to the summation order of the partials (fp64 gate 1e-9, fp32 1e-3)."""
+    import dist_worker
+    from trmf import session, synth
+    iters = 3
+    env = {'TRMF_NO_HV_TILE': '1', 'TRMF_CG': 'shard'}
+    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters, 'c4', env))
+    p, m0 = dist_worker._problem('c4')
+    monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
+    for dtype in (np.float32, np.float64):
+        name = np.dtype(dtype).name
+        model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
+        with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
+            s.run(iters); st = s.stats(iters); s.download()
+        W0, H0, T0, cg0 = out[0][name]
+        W1, H1, T1, cg1 = out[1][name]
+        assert np.array_equal(W0, W1) and np.array_equal(H0, H1) and np.array_equal(T0, T1) and cg0 == cg1
+        tol = 1e-9 if dtype == np.float64 else 1e-3
+        assert relfro(W0, model.W) < tol and relfro(H0, model.H) < tol and relfro(T0, model.lag_val) < 10 * tol
+        assert all(abs(a - b) <= (0 if dtype == np.float64 else 1) for a, b in zip(cg0, [x['cg_iter'] for x in st]))
 
 
 RCCL_SCRIPT = r"""
