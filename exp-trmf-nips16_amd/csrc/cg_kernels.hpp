@@ -180,24 +180,181 @@ __global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XStat
     }
 }
 
+// ---- AR + ridge part of the operator, tiled over (time x column group) in LDS ------------------------------
+// base = lambdaI*v + lambdaAR*AR'(AR(v)) for the unfused path (lag sets whose reach does not fit hv_tile_kernel's
+// whole-row tiles: the paper scripts' lags reach back 191 timestamps).  The AR operator never mixes latent
+// dimensions, so a workgroup owns TI consecutive timestamps of kArCols neighbouring columns: it stages the
+// operand rows [i0-midx, i0+TI+midx) of those columns once (every element of v is read from global memory
+// ~(TI+2 midx)/TI times instead of 2|L|+1 times), forms the residuals of rows [i0, i0+TI+midx) there
+// (the halo is recomputed, not exchanged) and applies the adjoint to its own rows.  Same arithmetic and rounding
+// sequence as ar_residual_kernel + the AR section apply_kernel used to carry (trmf.cpp:99-149).
+// FUSE_DIR: the operand is the new direction d + (beta-1) d + r (rf_tron.h:494-502), written once for the own rows.
+// Partial sums of r^2 (AR part of fun) and v^2 (ridge part) go to slot blockIdx.y * gridDim.x + blockIdx.x.
+constexpr int kArCols = 8;
+constexpr int kArThreads = 1024;     // one workgroup per CU (its LDS tile is ~100 KB at the paper's lag set): 16 wavefronts hide the LDS latency
+__host__ __device__ inline size_t ar_tile_lds_bytes(int TI, int midx, int nlag) {
+    return ((size_t)(TI + 2 * midx) * kArCols * sizeof(real) + (size_t)(TI + midx) * kArCols * sizeof(double) +
+            (size_t)nlag * kArCols * sizeof(real) + 63) / 16 * 16;
+}
+// fixed-order sum over a workgroup of kArThreads threads (16 wavefronts); identical in every thread
+__device__ __forceinline__ double block_allsum_wide(double v, double *smem /* >= 16 doubles */) {
+    v = wave_butterfly_sum(v);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0;
+#pragma unroll
+    for (int w = 0; w < kArThreads / 64; w++) r += smem[w];
+    __syncthreads();
+    return r;
+}
+template <bool FUSE_DIR>
+__global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, const XState *__restrict__ st,
+                                                             const double *__restrict__ Prr_cur,
+                                                             const double *__restrict__ Prr_prev, int np,
+                                                             const real *__restrict__ v, const real *__restrict__ rvec,
+                                                             real *__restrict__ dnew,
+                                                             const uint32_t *__restrict__ lag_set,
+                                                             const real *__restrict__ theta,
+                                                             real *__restrict__ base, double *__restrict__ Pbase, int TI) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ar_smem[];
+    __shared__ double smem[32];
+    const int tid = threadIdx.x, T = p.T, KP = p.KP, Hh = p.midx, nlag = p.nlag;
+    const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
+    real *vs = reinterpret_cast<real *>(ar_smem);                                   // vs[row][col]
+    double *rs = reinterpret_cast<double *>(ar_smem + (((size_t)rowsV * kArCols * sizeof(real) + 15) / 16 * 16));
+    real *ths = reinterpret_cast<real *>(rs + (size_t)rowsR * kArCols);             // ths[l][col]
+    real tmp = 0;
+    if (Prr_cur != nullptr) {
+        double a = 0, b = 0;
+        for (int i = tid; i < np; i += kArThreads) { a += Prr_cur[i]; if (FUSE_DIR) b += Prr_prev[i]; }
+        const real rho = (real)block_allsum_wide(a, smem);
+        if (cg_stopped(rho, st->cgtol)) return;
+        if (FUSE_DIR) {
+            const real rho_prev = (real)block_allsum_wide(b, smem);
+            tmp = rho / rho_prev - (real)1.0;                                        // rf_tron.h:495-497
+        }
+    }
+    const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
+    for (int e = tid; e < nlag * kArCols; e += kArThreads) {
+        const int l = e / kArCols, cc = e - l * kArCols, t = collog(c0 + cc, p.NT);
+        ths[e] = t < p.k ? theta[(size_t)t * nlag + l] : real(0);
+    }
+    // (1) operand rows -> LDS (zeros outside [0, T)); own rows of the new direction go out
+    double vv = 0, ar2 = 0;
+    for (int e = tid; e < rowsV * kArCols; e += kArThreads) {
+        const int rr = e / kArCols, cc = e - rr * kArCols, i = i0 - Hh + rr;
+        real x = 0;
+        if (i >= 0 && i < T) {
+            const size_t ge = (size_t)i * KP + c0 + cc;
+            x = v[ge];
+            if (FUSE_DIR) { x = fma(tmp, x, x); x = x + rvec[ge]; }
+            if (i >= i0 && i < i1) {
+                if (FUSE_DIR) dnew[ge] = x;
+                vv += (double)x * (double)x;
+            }
+        }
+        vs[e] = x;
+    }
+    __syncthreads();
+    const bool ar_on = nlag > 0 && p.lambdaAR > 0;
+    // (2) residuals of rows [i0, i0+TI+midx) (trmf.cpp:110-113 / 136-139): r = x_i - sum_l Theta_l x_{i-L_l}.
+    //     A thread keeps ONE column (kArThreads is a multiple of kArCols) and kArU rows at a time, so each Theta
+    //     element is read once per lag for kArU residuals; the lag offsets are wave-uniform (scalar cache, not LDS).
+    constexpr int kArU = 4, kRowStep = kArThreads / kArCols;
+    const int cc = tid % kArCols, r0 = tid / kArCols;
+    if (ar_on) {
+        for (int rb = r0; rb < rowsR; rb += kArU * kRowStep) {
+            double res[kArU];
+            const real *col[kArU];
+            bool on[kArU];
+#pragma unroll
+            for (int u = 0; u < kArU; u++) {
+                const int rr = rb + u * kRowStep, i = i0 + rr;
+                on[u] = rr < rowsR && i >= Hh && i < T;
+                col[u] = vs + (size_t)((on[u] ? rr : 0) + Hh) * kArCols + cc;
+                res[u] = (double)col[u][0];
+            }
+#pragma unroll 2
+            for (int l = 0; l < nlag; l++) {
+                const real th = ths[l * kArCols + cc];
+                const ptrdiff_t back = (ptrdiff_t)lag_set[l] * kArCols;
+#pragma unroll
+                for (int u = 0; u < kArU; u++) {
+                    const real prod = th * col[u][-back];
+                    res[u] -= (double)prod;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kArU; u++) {
+                const int rr = rb + u * kRowStep;
+                if (rr < rowsR) {
+                    const double rv = on[u] ? res[u] : 0.0;                   // rows outside [midx, T): exact zeros
+                    if (rr < TI) ar2 += rv * rv;
+                    rs[(size_t)rr * kArCols + cc] = rv;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // (3) base = lambdaI*v + lambdaAR*AR'(r) for the own rows: same rounding sequence as the reference's
+    //     time-ordered scatter loop (own-row term first, then the lags in order).  Residual rows outside [midx, T)
+    //     were stored as exact zeros, so the lagged terms need no range test.
+    for (int rb = r0; rb < i1 - i0; rb += kArU * kRowStep) {
+        real o[kArU];
+        const double *rcol[kArU];
+        bool on[kArU];
+#pragma unroll
+        for (int u = 0; u < kArU; u++) {
+            const int rr = rb + u * kRowStep, i = i0 + rr;
+            on[u] = rr < i1 - i0;
+            const int rq = on[u] ? rr : 0;
+            const real x = vs[(size_t)(rq + Hh) * kArCols + cc];
+            if (p.lambdaI == 0) o[u] = 0;
+            else if (p.lambdaI == 1) o[u] = x;
+            else o[u] = (real)(p.lambdaI * (double)x);
+            rcol[u] = rs + (size_t)rq * kArCols + cc;
+            if (ar_on && i >= Hh) o[u] = (real)((double)o[u] + p.lambdaAR * rcol[u][0]);
+        }
+        if (ar_on) {
+#pragma unroll 2
+            for (int l = 0; l < nlag; l++) {
+                const double lth = p.lambdaAR * (double)ths[l * kArCols + cc];
+                const size_t fwd = (size_t)lag_set[l] * kArCols;
+#pragma unroll
+                for (int u = 0; u < kArU; u++) o[u] = (real)((double)o[u] - rcol[u][fwd] * lth);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kArU; u++)
+            if (on[u]) base[(size_t)(i0 + rb + u * kRowStep) * KP + c0 + cc] = o[u];
+    }
+    ar2 = block_allsum_wide(ar2, smem);
+    vv = block_allsum_wide(vv, smem);
+    if (tid == 0) {
+        const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        Pbase[P_AR * (size_t)p.pstride + slot] = ar2;
+        Pbase[P_VV * (size_t)p.pstride + slot] = vv;
+    }
+}
+
 // ---- out = lambdaI*v + lambdaAR*AR'(v) + G.v (- b) ; partial of <dotwith, out> ----------------------
 // Multi-GPU (TrmfSessionImpl::cg_shard): every rank evaluates its own block of timestamps -- the k x k Gram per
 // timestamp is the only HBM-sized stream of a CG step, and the Hessian is block-diagonal there (trmf.cpp:269-288)
 // -- and the blocks of `out` and of the partial sums are all-gathered; everything else of the CG stays replicated.
 // grad (trmf.cpp:99-123 + 247-267) when minus_b, Hessian-vector product (trmf.cpp:125-149 + 269-288)
-// otherwise.  One thread per (row, column); `rpb` rows per block; the row's v is staged in LDS.
+// otherwise.  The AR + ridge part comes in as `base` (ar_tile_kernel); this kernel adds the cached-Gram product.
+// One thread per (row, column); `rpb` rows per block; the row's v is staged in LDS.
 // dot_mode 0: <out,out>   1: <v,out>
 __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__restrict__ st,
                                                     const double *__restrict__ Prr_cur, int np,
                                                     const real *__restrict__ v,
-                                                    const double *__restrict__ rAR,
-                                                    const uint32_t *__restrict__ lag_set,
-                                                    const real *__restrict__ theta,
+                                                    const real *__restrict__ base,
                                                     const real *__restrict__ G,
                                                     const real *__restrict__ Bv, int minus_b,
                                                     real *__restrict__ out, int dot_mode,
                                                     double *__restrict__ Pdot, int rpb,
                                                     int row0, int nrows, int slot0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char apply_smem[];   // k*k reals when the Gram is shared (gstride == 0)
     __shared__ double smem[256];
     __shared__ real vs[256];
     if (Prr_cur != nullptr) {
@@ -205,6 +362,12 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
         if (cg_stopped(rho, st->cgtol)) return;
     }
     const int k = p.k, KP = p.KP;
+    const bool shared_gram = p.gstride == 0;          // full-observation path: one H^T H for every timestamp
+    real *Gs = reinterpret_cast<real *>(apply_smem);
+    if (shared_gram) {
+        for (int e = threadIdx.x; e < k * k; e += 256) Gs[e] = G[e];
+        __syncthreads();
+    }
     const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;     // t: logical column
     const int tp = colpos(t, p.NT);                                 // its position in a vector row
     const bool active_lane = lr < rpb;
@@ -221,26 +384,18 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
         vs[threadIdx.x] = x;
         __syncthreads();
         if (active) {
-            // base part: same rounding sequence as the reference's time-ordered scatter loop
-            real o;
-            if (p.lambdaI == 0) o = 0;
-            else if (p.lambdaI == 1) o = x;
-            else o = (real)(p.lambdaI * (double)x);
-            if (p.nlag > 0 && p.lambdaAR > 0) {
-                if (i >= p.midx) o = (real)((double)o + p.lambdaAR * rAR[(size_t)i * KP + tp]);
-                for (int l = 0; l < p.nlag; l++) {
-                    const int ii = i + (int)lag_set[l];
-                    if (ii >= p.midx && ii < p.T)
-                        o = (real)((double)o - p.lambdaAR * rAR[(size_t)ii * KP + tp] *
-                                                   (double)theta[(size_t)t * p.nlag + l]);
-                }
-            }
+            real o = base[(size_t)i * KP + tp];                    // lambdaI*v + lambdaAR*AR'(v), ar_tile_kernel
             // cached Gram: sum_s G_i[s][t] * v_i[s]
-            const real *Gi = G + (size_t)i * p.gstride + t;
             const real *vi = vs + lr * k;
             double acc = 0;
+            if (shared_gram) {
 #pragma unroll 8
-            for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k] * (double)vi[s];
+                for (int s = 0; s < k; s++) acc += (double)Gs[s * k + t] * (double)vi[s];
+            } else {
+                const real *Gi = G + (size_t)i * p.gstride + t;
+#pragma unroll 8
+                for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k] * (double)vi[s];
+            }
             if (minus_b) {
                 const double bb = (double)Bv[(size_t)i * KP + t];
                 lq += (double)x * (acc - 2.0 * bb);                          // w.(Gw) - 2 b.w

@@ -94,6 +94,8 @@ struct TrmfSessionImpl {
     static constexpr int kEventRing = 64;
     int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
     int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), grid
+    int ar_TI = 64, nbar = 1;                 // unfused path: timestamps per ar_tile_kernel workgroup, its partial-sum slots
+    DevBuf<real> arbase;                      // lambdaI*v + lambdaAR*AR'(v) between ar_tile_kernel and apply_kernel
     XParams xp{};
 
     ~TrmfSessionImpl() {
@@ -247,7 +249,17 @@ struct TrmfSessionImpl {
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
         }
-        xp.pstride = std::max(kMaxPartials, nbt);
+        {   // unfused path: AR tile = the largest power of two of timestamps whose halo fits a 120 KB LDS budget
+            ar_TI = 512;
+            while (ar_TI > 32 && ar_tile_lds_bytes(ar_TI, midx, nlag) > 120 * 1024) ar_TI /= 2;
+            const size_t need = ar_tile_lds_bytes(ar_TI, midx, nlag);
+            if (allow_dyn_lds(ar_tile_kernel<true>, need, "AR operator (max lag too large)") ||
+                allow_dyn_lds(ar_tile_kernel<false>, need, "AR operator (max lag too large)"))
+                return kFail;
+            nbar = ((T + ar_TI - 1) / ar_TI) * (KP / kArCols);
+            if (arbase.alloc(NV)) return kFail;
+        }
+        xp.pstride = std::max(kMaxPartials, std::max(nbt, nbar));
         if (partials.alloc((size_t)P_NSLOTS * xp.pstride)) return kFail;
         xp.T = T; xp.k = k; xp.KP = KP; xp.NT = NT; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
@@ -634,22 +646,25 @@ struct TrmfSessionImpl {
            int minus_b, real *out, int dot_mode) {
         XState *st = xstate.p;
         double *Pb = partials.p;
+        const dim3 ar_grid((T + ar_TI - 1) / ar_TI, KP / kArCols);
+        const size_t ar_lds = ar_tile_lds_bytes(ar_TI, midx, nlag);
         if (fuse)
-            hipLaunchKernelGGL((ar_residual_kernel<true>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
-                               v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
+            hipLaunchKernelGGL((ar_tile_kernel<true>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, Pcur, Pprev, nbe,
+                               v, rvec, dnew, lag_set.p, theta.p, arbase.p, Pb, ar_TI);
         else
-            hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pprev, nbe,
-                               v, rvec, dnew, lag_set.p, theta.p, rAR.p, Pb);
+            hipLaunchKernelGGL((ar_tile_kernel<false>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, Pcur, Pprev, nbe,
+                               v, rvec, dnew, lag_set.p, theta.p, arbase.p, Pb, ar_TI);
+        const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : 0;        // shared Gram staged per workgroup
         if (!cg_shard) {
-            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
-                               lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, 0, T, 0);
+            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, Pcur, nbe, fuse ? dnew : v, arbase.p,
+                               Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, 0, T, 0);
             return 0;
         }
         // Gram product on this rank's timestamps only; its rows of `out` and its slots of the partial sums are
         // all-gathered (one grouped round), so every rank continues with identical vectors and scalars
         const int rb = (int)xbounds[comm->rank], re = (int)xbounds[comm->rank + 1];
-        hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), 0, stream, xp, st, Pcur, nbe, fuse ? dnew : v, rAR.p,
-                           lag_set.p, theta.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, rb, re - rb,
+        hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), ap_lds, stream, xp, st, Pcur, nbe, fuse ? dnew : v, arbase.p,
+                           Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, rb, re - rb,
                            comm->rank * apply_slots);
         TRMF_HIP_CHECK(hipGetLastError());
         std::vector<uint64_t> poff(comm->world + 1);
@@ -697,7 +712,7 @@ struct TrmfSessionImpl {
         }
         if (hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0)) return kFail;   // gradient, <g,g>, AR/ridge sums
         const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
-        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, ndot, g.p,
+        hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbar, ndot, g.p,
                            s.p, r.p, d0.p);
         real *dcur = d0.p, *dalt = d1.p;
         for (int it = 0; it < maxcg; it++) {

@@ -56,6 +56,9 @@ CONFIGS = {
     # python/exp-scripts/run_electricity.py:9-25 (k and lags as BASELINE.json states them)
     'c1': dict(n=370, T=26304, k=4, lags=[1, 2, 3], dense=True, dtype='float64',
                hyper=dict(lambdaI=0.5, lambdaAR=125.0, lambdaLag=2.0)),
+    # the shape python/exp-scripts/run_electricity.py:9-25 really trains at: k=60, 48 lags {1..24} u {168..191}, missing=0
+    'c1p': dict(n=370, T=26304, k=60, lags=list(range(1, 25)) + list(range(168, 192)), dense=True, dtype='float64',
+                hyper=dict(lambdaI=0.5, lambdaAR=125.0, lambdaLag=2.0)),
     'c2': dict(n=10000, T=5000, k=16, nlag=8, density=0.01, dtype='float32'),
     'c3': dict(n=100000, T=10000, k=40, nlag=16, density=0.01, dtype='float32'),
     'c5': dict(n=1000000, T=50000, k=64, nlag=32, density=0.001, dtype='float64'),
