@@ -83,7 +83,7 @@ struct TrmfSessionImpl {
     // full-observation path (missing == 0)
     bool full = false, dense = false;
     DevBuf<real> Yd_tn, Yd_nt;                // dense Y as T x n and as n x T (both row-major)
-    DevBuf<real> Bf, GSf, GSx;                // F-side right-hand sides (n x KP), shared Grams (k x k)
+    DevBuf<real> Bf, GSf, GSx, Uf;            // F-side right-hand sides (n x KP), shared Grams (k x k), Cholesky factor of GSf
     DevBuf<double> gemm_part, sgram_part;
     double trYTY = 0;
     static constexpr int kGemmChunks = 32, kSmallGramBlocks = 256;
@@ -173,7 +173,7 @@ struct TrmfSessionImpl {
         if (upload_padded(H, (const real *)Hm->val, n)) return kFail;
         if (theta.upload((const real *)LVm->val, (size_t)nlag * k)) return kFail;
         if (xstate.alloc(1) || log.alloc(kLogCap)) return kFail;
-        if (full && (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
+        if (full && (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || Uf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
                      sgram_part.alloc((size_t)kSmallGramBlocks * k * k)))
             return kFail;
         if (alloc_time_scratch()) return kFail;
@@ -544,14 +544,19 @@ struct TrmfSessionImpl {
                                out, rb, re, zero_row);
     }
     template <int NT_> void launch_dense_tn(const real *A, int K, int M, const real *B, real *out) {
-        // contraction chunks: enough workgroups to fill the chip even when there are only a few hundred output
-        // rows (Y^T W of a tall series matrix), within the partial buffer (kGemmChunks * max(n,T) rows)
-        const int xb = (M + 255) / 256;
+        // contraction chunks: enough workgroups (64 output rows each) to fill the chip even when there are only a few
+        // hundred output rows (Y^T W of a tall series matrix), at least 64 contracted rows per chunk, within the
+        // partial buffer (kGemmChunks * max(n,T) rows)
+        const int xb = (M + 63) / 64;
         const long long cap = (long long)kGemmChunks * std::max(n, T) / std::max(M, 1);
-        const int nchunk = (int)std::max<long long>(1, std::min<long long>({cap, (long long)K, std::max<long long>(kGemmChunks, 2048 / xb)}));
-        hipLaunchKernelGGL((dense_tn_kernel<NT_>), dim3(xb, nchunk), dim3(256), 0, stream, A, K, M, B, gemm_part.p);
-        hipLaunchKernelGGL(dense_tn_reduce_kernel, dim3((unsigned)(((size_t)M * KP + 3) / 4)), dim3(256), 0, stream,
-                           gemm_part.p, nchunk, M, KP, NT, k, out);
+        const int nchunk = (int)std::max<long long>(1, std::min<long long>({cap, (long long)std::max(1, K / 64), (1024 + xb - 1) / xb}));
+        hipLaunchKernelGGL((dense_tn_mfma_kernel<NT_>), dim3(xb, nchunk), dim3(256), 0, stream, A, K, M, B, gemm_part.p);
+        if (nchunk <= 16)       // few chunks: a thread per output; many (tall contraction, few outputs): a wavefront per output
+            hipLaunchKernelGGL(dense_tn_reduce_flat_kernel, dim3((unsigned)(((size_t)M * KP + 255) / 256)), dim3(256), 0, stream,
+                               gemm_part.p, nchunk, M, KP, NT, k, out);
+        else
+            hipLaunchKernelGGL(dense_tn_reduce_kernel, dim3((unsigned)(((size_t)M * KP + 3) / 4)), dim3(256), 0, stream,
+                               gemm_part.p, nchunk, M, KP, NT, k, out);
     }
     int y_times_factor(bool transposed, const real *X, real *out, uint32_t rb, uint32_t re) {
         if (!dense) {
@@ -577,10 +582,19 @@ struct TrmfSessionImpl {
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }
+    template <int NT_> void launch_small_gram(const real *A, int rows, int nb) {
+        hipLaunchKernelGGL((small_gram_mfma_kernel<NT_>), dim3(nb), dim3(256), 0, stream, A, rows, k, sgram_part.p);
+    }
     int small_gram(const real *A, int rows, real lambda, real *GS) {
-        const int nb = std::min(kSmallGramBlocks, std::max(1, rows));
-        hipLaunchKernelGGL(small_gram_kernel, dim3(nb), dim3(256), 0, stream, A, rows, KP, NT, k, sgram_part.p);
-        hipLaunchKernelGGL(small_gram_reduce_kernel, dim3((k * k + 3) / 4), dim3(256), 0, stream, sgram_part.p, nb, k, lambda, GS);
+        // one partial per wavefront (4 per workgroup), at least 64 rows each, kSmallGramBlocks slots in all
+        const int nb = std::max(1, std::min(kSmallGramBlocks / 4, rows / 256));
+        switch (NT) {
+            case 1: launch_small_gram<1>(A, rows, nb); break;
+            case 2: launch_small_gram<2>(A, rows, nb); break;
+            case 3: launch_small_gram<3>(A, rows, nb); break;
+            default: launch_small_gram<4>(A, rows, nb); break;
+        }
+        hipLaunchKernelGGL(small_gram_reduce_kernel, dim3((k * k + 3) / 4), dim3(256), 0, stream, sgram_part.p, nb * 4, k, lambda, GS);
         return 0;
     }
     int fsolve_full(PhaseEvents &ev) {
@@ -589,9 +603,11 @@ struct TrmfSessionImpl {
         if (y_times_factor(true, W.p, Bf.p, dense ? 0u : rb, dense ? (uint32_t)n : re)) return kFail;   // Y^T W
         small_gram(W.p, T, (real)lambdaI, GSf.p);                                                       // W^T W + lambda I
         if (re > rb) {
-            const int rpw = solve_shared_rows_per_block(k);            // 64..256 rows per workgroup: LDS <= 64 KB
-            hipLaunchKernelGGL(solve_shared_kernel, dim3((re - rb + rpw - 1) / rpw), dim3(rpw), solve_shared_lds_bytes(k, rpw),
-                               stream, GSf.p, Bf.p + (size_t)rb * KP, H.p + (size_t)rb * KP, (int)(re - rb), k, KP, NT);
+            const size_t ulds = (size_t)k * k * sizeof(real);          // <= 32 KB
+            hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
+            const int nrows = (int)(re - rb), nblk = std::max(1, std::min(2048, (nrows + 3) / 4));
+            hipLaunchKernelGGL(solve_rows_kernel, dim3(nblk), dim3(256), ulds, stream, Uf.p, Bf.p + (size_t)rb * KP,
+                               H.p + (size_t)rb * KP, nrows, k, KP, NT);
         }
         TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
         TRMF_HIP_CHECK(hipGetLastError());
