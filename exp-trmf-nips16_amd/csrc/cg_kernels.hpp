@@ -24,7 +24,7 @@ namespace trmf {
 constexpr int kCgHistCap = 64;    // CG iterations the fused path can record (the reference folds to 20)
 
 struct XState {
-    double f, fnew, gnorm, cg_rnorm, actred, prered, gs, sr;
+    double f, fnew, gnorm, cg_rnorm, actred, prered, gs, sr, delta;   // delta: trust-region bound after the step (rf_tron.h:195-215)
     double loss0, loss1;          // sum of squared residuals at w and at w_new (reduce_rows_kernel)
     real cgtol;
     int cg_iter, accepted;
@@ -38,7 +38,8 @@ constexpr int kCgRunning = 0x7fffffff;
 // partial-sum arrays: Pbase[slot * kMaxPartials + block]
 enum PartialSlot { P_AR = 0, P_VV = 1, P_DOT = 2, P_RR0 = 3, P_RR1 = 4, P_GS = 5, P_SR = 6, P_LQ = 7,
                    P_CG0 = 8,    // fused CG path: <d,Hd>, <r,Hd>, <Hd,Hd> of even iterations (P_CG0..+2), odd ones (+3..+5)
-                   P_NSLOTS = 14 };
+                   P_SS = 14,    // <s,s> (step norm of the TRON line)
+                   P_NSLOTS = 15 };
 
 struct XParams {
     int T, k, KP, NT, nlag, midx;      // NT = KP/16: vectors use the column-interleaved layout (colpos)
@@ -986,18 +987,19 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__re
     __shared__ double smem[256];
     const real *__restrict__ r = st->r_parity ? r_odd : r_even;   // fused CG: the launch that stopped wrote it
     const size_t N = (size_t)p.T * p.KP;
-    double gs = 0, sr = 0;
+    double gs = 0, sr = 0, ss = 0;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
         const real sv = s[e];
         w_new[e] = w[e] + sv;
         gs += (double)g[e] * (double)sv;
         sr += (double)sv * (double)r[e];
+        ss += (double)sv * (double)sv;
     }
-    gs = block_allsum(gs, smem);
-    sr = block_allsum(sr, smem);
+    block_allsum3(gs, sr, ss, smem);
     if (threadIdx.x == 0) {
         Pbase[P_GS * (size_t)p.pstride + blockIdx.x] = gs;
         Pbase[P_SR * (size_t)p.pstride + blockIdx.x] = sr;
+        Pbase[P_SS * (size_t)p.pstride + blockIdx.x] = ss;
     }
 }
 
@@ -1017,6 +1019,7 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
     const double gs = (double)(real)sum_partials(Pbase + P_GS * (size_t)p.pstride, np, smem);
     const double sr = (double)(real)sum_partials(Pbase + P_SR * (size_t)p.pstride, np, smem);
     const double sHs = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
+    const double snorm = sqrt((double)(real)sum_partials(Pbase + P_SS * (size_t)p.pstride, np, smem));
     const double rho = Prr_final ? (double)(real)sum_partials(Prr_final, np, smem)
                                  : (double)(real)st->rho_hist[st->cg_iter];              // fused CG path
     const double f = st->f;
@@ -1034,10 +1037,21 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
         st->prered = prered; st->actred = actred;
         st->accepted = accept ? 1 : 0;
         st->cg_rnorm = sqrt(rho);
+        // trust-region bound the reference prints (rf_tron.h:195-215; it never constrains the step here: the folded
+        // parameters of trmf.cpp:603-606 run a pure CG pass): delta0 = |g|, first iteration min(delta, |s|), then the
+        // update by the ratio of actual to predicted reduction
+        double delta = fmin(st->gnorm, snorm);
+        const double curv = fnew - f - gs;
+        const double alpha = curv <= 0 ? 4.0 : fmax(0.25, -0.5 * (gs / curv));
+        if (actred < 1e-4 * prered) delta = fmin(fmax(alpha, 0.25) * snorm, 0.5 * delta);
+        else if (actred < 0.25 * prered) delta = fmax(0.25 * delta, fmin(alpha * snorm, 0.5 * delta));
+        else if (actred < 0.75 * prered) delta = fmax(0.25 * delta, fmin(alpha * snorm, 4.0 * delta));
+        else delta = fmax(delta, fmin(alpha * snorm, 4.0 * delta));
+        st->delta = delta;
         if (log_x) {                                    // iteration record written here: no copies on the stream
             log_x->f = f; log_x->fnew = fnew; log_x->gnorm = st->gnorm; log_x->cg_rnorm = sqrt(rho);
             log_x->actred = actred; log_x->prered = prered; log_x->gs = gs; log_x->sr = sr;
-            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0;
+            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0; log_x->delta = delta;
             log_norms[0] = log_norms[1] = log_norms[2] = -1.0;      // ||.||^2 lines are off in this mode
         }
     }

@@ -99,7 +99,14 @@ inline RcclApi &rccl_api() { static RcclApi api; return api; }
 struct RcclComm : Comm {
     RcclApi::CommT comm = nullptr;
     RcclComm() { call_when_single = true; }   // keeps the RCCL call path testable on a 1-GPU box
-    ~RcclComm() override { if (comm) rccl_api().CommDestroy(comm); }
+    int device = 0;                           // HIP device the communicator was created on
+    ~RcclComm() override {
+        if (!comm) return;
+        int prev = -1;
+        if (hipGetDevice(&prev) == hipSuccess && prev != device) (void)hipSetDevice(device);
+        rccl_api().CommDestroy(comm);
+        if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
+    }
     int group_begin() override { return rccl_api().GroupStart() == 0 ? 0 : kFail; }
     int group_end() override {
         const int rc = rccl_api().GroupEnd();

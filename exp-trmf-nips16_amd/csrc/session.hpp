@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 #include "../../include/trmf_abi.h"
@@ -30,7 +31,7 @@
 
 namespace trmf {
 
-Comm *active_comm();   // trmf_abi.hip
+std::shared_ptr<Comm> active_comm();   // trmf_abi.hip
 
 template <typename T> struct DevBuf {
     T *p = nullptr;
@@ -73,7 +74,7 @@ struct TrmfSessionImpl {
     double eps_cg = 0.1;
     int iter = 0;                // ALS iterations done so far
     // distribution
-    Comm *comm = nullptr;
+    std::shared_ptr<Comm> comm;      // shared with the library: outlives trmf_dist_finalize() while the session lives
     std::vector<uint64_t> fbounds, xbounds;   // row partitions of items / timestamps
     // device
     hipStream_t stream = nullptr;
@@ -828,7 +829,7 @@ struct TrmfSessionImpl {
                         XState hx;
                         (void)hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost);
                         fprintf(stdout, "iter  1 act %5.3e pre %5.3e delta %5.3e f %5.3e |g| %5.3e CG %3d |g| %5.3e\n",
-                                hx.actred, hx.prered, hx.gnorm, hx.f, hx.gnorm, hx.cg_iter, hx.cg_rnorm);
+                                hx.actred, hx.prered, hx.delta, hx.f, hx.gnorm, hx.cg_iter, hx.cg_rnorm);
                         fflush(stdout);
                     }
                 }
@@ -865,7 +866,7 @@ struct TrmfSessionImpl {
             TrmfIterStats &o = out[q];
             o.normF = hl.normF; o.normX = hl.normX; o.normLV = hl.normLV;
             o.f = hl.x.f; o.fnew = hl.x.fnew; o.actred = hl.x.actred; o.prered = hl.x.prered;
-            o.gnorm = hl.x.gnorm; o.cg_rnorm = hl.x.cg_rnorm; o.cg_iter = hl.x.cg_iter; o.accepted = hl.x.accepted;
+            o.gnorm = hl.x.gnorm; o.cg_rnorm = hl.x.cg_rnorm; o.cg_iter = hl.x.cg_iter; o.accepted = hl.x.accepted; o.delta = hl.x.delta;
             o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = 0;
             (void)hipEventElapsedTime(&o.ms_F, ev.f0, ev.f1);
             (void)hipEventElapsedTime(&o.ms_F_kernel, ev.fk0, ev.fk1);

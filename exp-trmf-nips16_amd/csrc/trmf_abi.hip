@@ -22,9 +22,11 @@ void set_error(const std::string &msg) {
 }
 
 static int g_device = 0;
-static SelfComm g_self;
-static std::unique_ptr<Comm> g_comm;
-Comm *active_comm() { return g_comm ? g_comm.get() : &g_self; }
+static std::shared_ptr<Comm> g_self = std::make_shared<SelfComm>();
+static std::shared_ptr<Comm> g_comm;
+// A session shares ownership of the communicator it was created under, so trmf_dist_finalize() before
+// trmf_session_destroy() leaves the session's communicator alive until the session goes away.
+std::shared_ptr<Comm> active_comm() { return g_comm ? g_comm : g_self; }
 
 static bool bind_device() {
     int cnt = 0;
@@ -38,6 +40,17 @@ static bool bind_device() {
     }
     return true;
 }
+// Every entry point that touches the device selects the library's device (trmf_set_device) for its duration and
+// puts the caller's current device back on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    DeviceGuard() {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = bind_device();
+    }
+    ~DeviceGuard() { if (prev >= 0 && prev != g_device) (void)hipSetDevice(prev); }
+};
 
 // check_dimension, trmf.cpp:561-596 (same messages, same order)
 static bool check_dimension(const PyMatrix *Y, const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
@@ -62,7 +75,7 @@ static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t l
     if (Y->type != TRMF_SPARSE && Y->type != TRMF_DENSE_ROWMAJOR && Y->type != TRMF_DENSE_COLMAJOR) { fprintf(stderr, "[ERR MSG]: unsupported Y matrix type %d\n", (int)Y->type); pass = false; }
     if (W->cols < 1 || W->cols > (uint64_t)kMaxRank) { fprintf(stderr, "[ERR MSG]: rank k=%ld outside the supported range 1..%d\n", (long)W->cols, kMaxRank); pass = false; }
     if (lag_size > (uint32_t)kMaxLags) { fprintf(stderr, "[ERR MSG]: |lag_set|=%u exceeds the supported %d\n", lag_size, kMaxLags); pass = false; }
-    if (Y->nnz >= (1ull << 32) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
+    if ((Y->type == TRMF_SPARSE && Y->nnz >= (1ull << 32)) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
     // gathered factor rows are addressed with 32-bit byte offsets (gram_ring): tables up to 4 GiB
     const uint64_t rowbytes = (uint64_t)padded_rank((int)W->cols) * sizeof(real);
     if ((Y->rows + 1) * rowbytes > 0xffffffffull || (Y->cols + 1) * rowbytes > 0xffffffffull ||
@@ -72,15 +85,22 @@ static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t l
     return pass;
 }
 
+// The reference's dimension check plus this build's own limits (include/trmf_abi.h lists them); diagnostics on stderr.
+static bool validate_problem(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size, const PyMatrix *W,
+                             const PyMatrix *H, const PyMatrix *LV, int32_t missing) {
+    if (!check_dimension(Y, W, H, LV, lag_size)) { set_error("dimension check failed"); return false; }
+    if (!check_device_limits(Y, W, lag_size, missing)) { set_error("unsupported problem"); return false; }
+    for (uint32_t l = 1; l < lag_size; l++)
+        if (lag_set[l] < lag_set[l - 1]) { fprintf(stderr, "[ERR MSG]: lag_set must be ascending\n"); set_error("lag_set not ascending"); return false; }
+    if (lag_size && lag_set[lag_size - 1] >= Y->rows) { fprintf(stderr, "[ERR MSG]: max lag >= number of timestamps\n"); set_error("lag too large"); return false; }
+    return true;
+}
+
 static TrmfSessionImpl *make_session(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
                                      const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
                                      double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
                                      int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
-    if (!check_dimension(Y, W, H, LV, lag_size)) { set_error("dimension check failed"); return nullptr; }
-    if (!check_device_limits(Y, W, lag_size, missing)) { set_error("unsupported problem"); return nullptr; }
-    for (uint32_t l = 1; l < lag_size; l++)
-        if (lag_set[l] < lag_set[l - 1]) { fprintf(stderr, "[ERR MSG]: lag_set must be ascending\n"); set_error("lag_set not ascending"); return nullptr; }
-    if (lag_size && lag_set[lag_size - 1] >= Y->rows) { fprintf(stderr, "[ERR MSG]: max lag >= number of timestamps\n"); set_error("lag too large"); return nullptr; }
+    if (!validate_problem(Y, lag_set, lag_size, W, H, LV, missing)) return nullptr;
     if (!bind_device()) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
     std::unique_ptr<TrmfSessionImpl> s(new TrmfSessionImpl());
     s->lambdaI = lambdaI; s->lambdaAR = lambdaAR; s->lambdaLag = lambdaLag;
@@ -125,9 +145,15 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
         fprintf(stdout, "\n");
         fflush(stdout);
     }
-    // Quirk Q1: with warm_start == 0 the reference trains on private copies and the
-    // caller's arrays come back unchanged (trmf.cpp:552-558).  Observable behaviour reproduced.
-    if (!warm_start) return;
+    // Quirk Q1: with warm_start == 0 the reference trains on private randomly initialised copies
+    // and the caller's arrays come back unchanged (trmf.cpp:552-558).  Reproduced as far as a caller can observe
+    // it through the arrays: the problem is validated (same diagnostics as a warm start), nothing is trained and
+    // nothing is written.  The reference's ">> iter" lines of that discarded run are not reproduced.
+    if (!warm_start) {
+        (void)validate_problem(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, missing);
+        return;
+    }
+    DeviceGuard guard;                               // device of this library for the call, the caller's afterwards
     TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
                                       lambdaLag, period_W, period_H, period_Lag, missing, verbose);
     if (s) s->log_norms = verbose > 0;       // the norm lines exist only under verbose (trmf.cpp:659-688)
@@ -171,27 +197,38 @@ TrmfSession *trmf_session_create(const PyMatrix *Y, const uint32_t *lag_set, uin
                                  const PyMatrix *W, const PyMatrix *H, const PyMatrix *lag_val,
                                  double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
                                  int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
+    DeviceGuard guard;
     return reinterpret_cast<TrmfSession *>(make_session(Y, lag_set, lag_size, W, H, lag_val, lambdaI, lambdaAR,
                                                         lambdaLag, period_W, period_H, period_Lag, missing, verbose));
 }
 #define IMPL(s) reinterpret_cast<TrmfSessionImpl *>(s)
 
-int32_t trmf_session_run(TrmfSession *s, int32_t iters) { return s ? IMPL(s)->run(iters) : kFail; }
+int32_t trmf_session_run(TrmfSession *s, int32_t iters) {
+    if (!s) return kFail;
+    DeviceGuard guard;
+    return guard.ok ? IMPL(s)->run(iters) : kFail;
+}
 int32_t trmf_session_log_norms(TrmfSession *s, int32_t on) {
     if (!s) return kFail;
     IMPL(s)->log_norms = on != 0;
     return 0;
 }
-int32_t trmf_session_sync(TrmfSession *s) { return s ? IMPL(s)->sync() : kFail; }
+int32_t trmf_session_sync(TrmfSession *s) {
+    if (!s) return kFail;
+    DeviceGuard guard;
+    return guard.ok ? IMPL(s)->sync() : kFail;
+}
 int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew) {
     if (!s || !Ynew) { set_error("null session or block"); return kFail; }
-    if (!bind_device()) return kFail;
-    return IMPL(s)->append_rows(Ynew);
+    DeviceGuard guard;
+    return guard.ok ? IMPL(s)->append_rows(Ynew) : kFail;
 }
 int32_t trmf_session_rows(TrmfSession *s) { return s ? IMPL(s)->T : kFail; }
 
 int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val) {
     if (!s) return kFail;
+    DeviceGuard guard;
+    if (!guard.ok) return kFail;
     TrmfSessionImpl *t = IMPL(s);
     if (t->sync()) return kFail;
     if (W && (W->rows != (uint64_t)t->T || W->cols != (uint64_t)t->k || W->type != TRMF_DENSE_ROWMAJOR)) { set_error("W shape/layout mismatch"); return kFail; }
@@ -205,12 +242,19 @@ int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix
 }
 
 int32_t trmf_session_stats(TrmfSession *s, TrmfIterStats *out, int32_t cap) {
-    return (s && out && cap > 0) ? IMPL(s)->stats(out, cap) : 0;
+    if (!(s && out && cap > 0)) return 0;
+    DeviceGuard guard;
+    return guard.ok ? IMPL(s)->stats(out, cap) : 0;
 }
-double trmf_session_objective(TrmfSession *s) { return s ? IMPL(s)->objective() : NAN; }
+double trmf_session_objective(TrmfSession *s) {
+    if (!s) return NAN;
+    DeviceGuard guard;
+    return guard.ok ? IMPL(s)->objective() : NAN;
+}
 double trmf_session_fsolve_bytes(TrmfSession *s) { return s ? IMPL(s)->fsolve_bytes() : 0.0; }
 void trmf_session_destroy(TrmfSession *s) {
     if (!s) return;
+    DeviceGuard guard;
     (void)IMPL(s)->sync();
     delete IMPL(s);
 }
@@ -228,13 +272,14 @@ int32_t trmf_dist_get_unique_id(void *out_id) {
 
 int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id_bytes) {
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world"); return kFail; }
-    if (!bind_device()) return kFail;
+    DeviceGuard guard;
+    if (!guard.ok) return kFail;
     RcclApi &api = rccl_api();
     if (!api.load()) return kFail;
     RcclApi::UniqueId id;
     std::memcpy(&id, id_bytes, TRMF_UNIQUE_ID_BYTES);
-    std::unique_ptr<RcclComm> c(new RcclComm());
-    c->rank = rank; c->world = world;
+    std::shared_ptr<RcclComm> c = std::make_shared<RcclComm>();
+    c->rank = rank; c->world = world; c->device = g_device;
     const int rc = api.CommInitRank(&c->comm, world, id, rank);
     if (rc != 0) { set_error(std::string("ncclCommInitRank: ") + api.GetErrorString(rc)); c->comm = nullptr; return kFail; }
     g_comm = std::move(c);
@@ -243,7 +288,7 @@ int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id_bytes) {
 
 int32_t trmf_dist_init_callback(int32_t rank, int32_t world, trmf_allgatherv_fn fn, void *ctx) {
     if (world < 1 || rank < 0 || rank >= world || !fn) { set_error("bad rank/world/callback"); return kFail; }
-    std::unique_ptr<CallbackComm> c(new CallbackComm());
+    std::shared_ptr<CallbackComm> c = std::make_shared<CallbackComm>();
     c->rank = rank; c->world = world; c->fn = fn; c->ctx = ctx;
     g_comm = std::move(c);
     return 0;

@@ -8,9 +8,9 @@ the C++ library (csrc/comm.hpp).  No reference counterpart: the reference is sin
     import torch.distributed as dist                     # torch FIRST (see note below)
     from trmf import dist as tdist
     dist.init_process_group('nccl', ...)
-    tdist.init_rccl(np.float32)                          # every rank
+    tdist.init_rccl()                                    # every rank; both element-type libraries, device = LOCAL_RANK
     ... Session(...) / trmf.train(...)                   # identical inputs on every rank
-    tdist.finalize(np.float32)
+    tdist.finalize()
 
 Note: import torch before this package touches the GPU so that the process binds to ONE HIP/RCCL
 runtime (torch bundles its own copies under the same sonames).
@@ -22,22 +22,34 @@ import numpy as np
 from . import session
 
 
-def init_rccl(dtype=np.float32, device=None):
-    """Create the library's RCCL communicator on every rank of the default torch process group."""
+def _dtypes(dtype):
+    """``dtype=None`` means both element-type libraries: each trmf_float{32,64}.so keeps its own communicator."""
+    return (np.float32, np.float64) if dtype is None else (dtype,)
+
+
+def init_rccl(dtype=None, device=None):
+    """Create the library's RCCL communicator(s) on every rank of the default torch process group.
+
+    ``dtype=None`` (default) initialises both element-type libraries, so that fp32 and fp64 training are both sharded;
+    ``device`` defaults to ``LOCAL_RANK`` (one process per GPU, as torchrun launches them)."""
+    import os
     import torch.distributed as dist
-    lib = session.lib_for(dtype)
     rank, world = dist.get_rank(), dist.get_world_size()
-    if device is not None and lib.trmf_set_device(int(device)) != 0:
-        raise RuntimeError(lib.trmf_last_error().decode())
-    ident = [None]
-    if rank == 0:
-        buf = ctypes.create_string_buffer(128)
-        if lib.trmf_dist_get_unique_id(buf) != 0:
+    if device is None:
+        device = int(os.environ.get('LOCAL_RANK', 0))
+    for dt in _dtypes(dtype):
+        lib = session.lib_for(dt)
+        if lib.trmf_set_device(int(device)) != 0:
             raise RuntimeError(lib.trmf_last_error().decode())
-        ident = [buf.raw]
-    dist.broadcast_object_list(ident, src=0)
-    if lib.trmf_dist_init(rank, world, ident[0]) != 0:
-        raise RuntimeError(lib.trmf_last_error().decode())
+        ident = [None]
+        if rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            if lib.trmf_dist_get_unique_id(buf) != 0:
+                raise RuntimeError(lib.trmf_last_error().decode())
+            ident = [buf.raw]
+        dist.broadcast_object_list(ident, src=0)
+        if lib.trmf_dist_init(rank, world, ident[0]) != 0:
+            raise RuntimeError(lib.trmf_last_error().decode())
     return rank, world
 
 
@@ -78,6 +90,8 @@ def init_host_staged(dtype=np.float32, group=None):
     return rank, world
 
 
-def finalize(dtype=np.float32):
-    session.lib_for(dtype).trmf_dist_finalize()
-    _keepalive.pop((id(session.lib_for(dtype)), 'cb'), None)
+def finalize(dtype=None):
+    """Drop the library communicator(s).  Sessions created under one keep it alive until they are closed."""
+    for dt in _dtypes(dtype):
+        session.lib_for(dt).trmf_dist_finalize()
+        _keepalive.pop((id(session.lib_for(dt)), 'cb'), None)

@@ -19,7 +19,8 @@ class TrmfIterStats(ctypes.Structure):
                 ('f', c_double), ('fnew', c_double), ('actred', c_double), ('prered', c_double),
                 ('gnorm', c_double), ('cg_rnorm', c_double),
                 ('cg_iter', c_int32), ('accepted', c_int32),
-                ('ms_F', c_float), ('ms_X', c_float), ('ms_LV', c_float), ('ms_F_kernel', c_float)]
+                ('ms_F', c_float), ('ms_X', c_float), ('ms_LV', c_float), ('ms_F_kernel', c_float),
+                ('delta', c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

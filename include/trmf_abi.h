@@ -75,8 +75,26 @@ typedef struct {
  * (trmf.cpp:647-693).  Outputs are written in place; Y and lag_set are never written.
  * Dimension/layout violations print the reference's "[ERR MSG]" lines on stderr and return
  * without touching the outputs (trmf.cpp:561-596,632-634).  warm_start == 0 reproduces the
- * reference's observable behaviour: the caller's arrays are not
- * updated.  `threads` is accepted and ignored (no OpenMP on the device path).
+ * reference's observable behaviour: the problem is validated, the
+ * caller's arrays are not updated (the reference trains private random copies and discards
+ * them; that discarded run and its ">> iter" lines are not reproduced).  `threads` is accepted
+ * and ignored (no OpenMP on the device path).
+ *
+ * Checks beyond the reference's (each prints one "[ERR MSG]: ..." line and returns like a
+ * dimension error; the reference aborts on an assert, reads out of bounds or has no such limit):
+ *   - missing != 0 with a dense Y                  (reference: assert, rf_matrix.h:180)
+ *   - lag_set not ascending, max lag >= rows of Y  (reference: out-of-bounds reads)
+ *   - rank k outside 1..64, more than 128 lags
+ *   - a SPARSE Y with nnz >= 2^32; Y with >= 2^24 - 1 rows or columns, or a factor table
+ *     (rows+1) x 16*ceil(k/16) elements above 4 GiB     (32-bit device offsets)
+ *   - a lag reach / lag count whose LDS tiles exceed 160 KB per workgroup (session creation)
+ *
+ * Deliberate differences inside the X-solve (documented in DESIGN.md section 1): the TRON loop of
+ * the reference (rf_tron.h:134-254, folded to ONE outer iteration by trmf.cpp:603-606) retries a
+ * rejected step without changing anything (quirk Q3); here a rejected step leaves W unchanged
+ * and the iteration goes on.  The acceptance test uses the exact quadratic identity
+ * f(w+s) - f(w) = g.s + s.Hs/2 instead of a second pass over the observations, so `actred`
+ * agrees with the reference's to rounding, not bit for bit.
  * verbose >= 1 prints the reference's parameter dump on stdout and the per-half-step
  * ">> iter i F|X|LV v" lines on stderr; verbose >= 2 adds the TRON line on stdout.          */
 TRMF_API void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_size,
@@ -107,6 +125,7 @@ typedef struct {
     int32_t cg_iter, accepted;
     float ms_F, ms_X, ms_LV;               /* HIP-event time of each phase on the solver stream */
     float ms_F_kernel;                     /* HIP-event time of the F-solve kernel alone       */
+    double delta;                          /* trust-region bound of the TRON line (rf_tron.h:195-219) */
 } TrmfIterStats;
 
 typedef struct TrmfSession TrmfSession;

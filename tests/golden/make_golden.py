@@ -25,6 +25,7 @@ import oracle_py as O          # noqa: E402
 from trmf import synth         # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
+LAST_TRON = None      # act, pre, delta, |g|, CG residual norm of every TRON line of the last reference run (rf_tron.h:219)
 
 
 class capture_fds(object):
@@ -57,11 +58,14 @@ def run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2), m
         m = re.match(r'>> iter (\d+) (F|X|LV) (\S+)$', line.strip())
         if m:
             {'F': normF, 'X': normX, 'LV': normLV}[m.group(2)][int(m.group(1)) - 1] = float(m.group(3))
-    cg, fx = [], []
+    cg, fx, tron = [], [], []
     for line in cap.out:
-        m = re.match(r'iter\s+\d+ act \S+ pre \S+ delta \S+ f (\S+) \|g\| \S+ CG\s+(\d+)', line.strip())
+        m = re.match(r'iter\s+\d+ act (\S+) pre (\S+) delta (\S+) f (\S+) \|g\| (\S+) CG\s+(\d+) \|g\| (\S+)', line.strip())
         if m:
-            fx.append(float(m.group(1))); cg.append(int(m.group(2)))
+            fx.append(float(m.group(4))); cg.append(int(m.group(6)))
+            tron.append([float(m.group(i)) for i in (1, 2, 3, 5, 7)])          # act, pre, delta, |g|, CG residual norm
+    global LAST_TRON
+    LAST_TRON = np.array(tron)
     return W, H, Th, normF, normX, normLV, np.array(cg, dtype=np.int32), np.array(fx)
 
 
@@ -82,7 +86,7 @@ def make_full_case(name, n, T, k, lag_set, dtype, max_iter, seed=0, hyper=None, 
     W, H, Th, nF, nX, nLV, cg, fx = run_reference(Y, lag_set, W0, H0, Th0, hyper, max_iter, missing=False)
     path = os.path.join(OUT, name + '.npz')
     common = dict(shape=np.array([T, n]), lag_set=lag_set, W0=W0, H0=H0, Th0=Th0, W=W, H=H, Th=Th,
-                  normF=nF, normX=nX, normLV=nLV, cg_iter=cg, f_x=fx, objective=np.array(np.nan), missing=np.array(0),
+                  normF=nF, normX=nX, normLV=nLV, cg_iter=cg, f_x=fx, tron=LAST_TRON, objective=np.array(np.nan), missing=np.array(0),
                   lambdaI=hyper['lambdaI'], lambdaAR=hyper['lambdaAR'], lambdaLag=hyper['lambdaLag'], max_iter=np.array(max_iter))
     if sparse_density is not None:
         np.savez_compressed(path, Y_indptr=Y.indptr.astype(np.int64), Y_indices=Y.indices.astype(np.int32), Y_data=Y.data, **common)
@@ -111,7 +115,7 @@ def make_case(name, n, T, k, lag_set, density, dtype, max_iter, seed=0, hyper=No
     np.savez_compressed(
         path, Y_indptr=Y.indptr.astype(np.int64), Y_indices=Y.indices.astype(np.int32), Y_data=Y.data,
         shape=np.array([T, n]), lag_set=lag_set, W0=W0, H0=H0, Th0=Th0, W=W, H=H, Th=Th,
-        normF=nF, normX=nX, normLV=nLV, cg_iter=cg, f_x=fx, objective=np.array(J),
+        normF=nF, normX=nX, normLV=nLV, cg_iter=cg, f_x=fx, tron=LAST_TRON, objective=np.array(J),
         lambdaI=hyper['lambdaI'], lambdaAR=hyper['lambdaAR'], lambdaLag=hyper['lambdaLag'],
         max_iter=np.array(max_iter))
     print('{:>14s}: T={} n={} k={} nnz={} {} iters={} cg={} J={:.6g} ({} KB)'.format(

@@ -128,3 +128,23 @@ def test_no_gpu_means_loud_failure_not_cpu_fallback(capfd, have_gpu):
     assert np.array_equal(model.W, W0) and np.array_equal(model.H, H0)      # nothing computed on the host
     with pytest.raises(RuntimeError, match='no HIP device'):
         session.Session(Y, model, missing=True)
+
+
+def test_cold_start_validates_but_never_writes(capfd):
+    """warm_start == 0 (quirk Q1 of the reference): the caller's arrays are never updated, but the problem is still
+    validated -- a dimension error prints the reference's diagnostics."""
+    from ctypes import POINTER, byref, c_uint32
+    from trmf import session
+    from trmf.rf_util import PyMatrix
+    lib = session.lib_for(np.float32)
+    Y = smat.random(30, 20, density=0.3, random_state=np.random.RandomState(0), format='csr', dtype=np.float32)
+    W = np.ones((29, 4), np.float32); H = np.ones((20, 4), np.float32); Th = np.ones((2, 4), np.float32, order='F')   # W has a row too few
+    lags = np.array([1, 2], dtype=np.uint32)
+    pyY, pyW, pyH, pyT = PyMatrix(Y), PyMatrix(W), PyMatrix(H), PyMatrix(Th)
+    get = lambda m: m.py_buf['val'].copy()
+    before = [get(pyW), get(pyH), get(pyT)]
+    lib.c_trmf_train(byref(pyY), lags.ctypes.data_as(POINTER(c_uint32)), 2, byref(pyW), byref(pyH), byref(pyT), 0,
+                     0.5, 50.0, 0.5, 2, 1, 1, 2, 1, 1, 0)
+    err = capfd.readouterr().err
+    assert 'Y.rows (30) != W.rows (29)' in err
+    assert all(np.array_equal(a, get(m)) for a, m in zip(before, (pyW, pyH, pyT)))

@@ -126,8 +126,9 @@ p = synth.sparse_problem(n=500, T=300, k=8, nlag=3, density=0.05, dtype=np.float
 m = synth.initial_model(p['Y'], p['lag_set'], 8, seed=2)
 a = make_model(m.W, m.H, m.lag_val, p['lag_set'])
 with session.Session(p['Y'], a, missing=True, **synth.HYPER) as s:
-    s.run(2); s.download()
-lib.trmf_dist_finalize()
+    s.run(1)
+    lib.trmf_dist_finalize()          # the session keeps the communicator it was created under alive
+    s.run(1); s.download()
 b = make_model(m.W, m.H, m.lag_val, p['lag_set'])
 with session.Session(p['Y'], b, missing=True, **synth.HYPER) as s:
     s.run(2); s.download()

@@ -78,9 +78,22 @@ def test_session_log_matches_reference_observables(name):
         assert cg.tolist() == g['cg_iter'].tolist()
     assert all(x['accepted'] == 1 for x in st)
     assert np.allclose([x['f'] for x in st], g['f_x'], rtol=2e-3)   # %5.3e in the TRON line
+    # the rest of the TRON line (rf_tron.h:219): act, pre, delta, |g|, CG residual norm -- printed with 4 digits; the
+    # reductions are differences of O(f) quantities, so their own gate is relative to f
+    tron = g['tron']
+    loose = 5e-3 if g['dtype'] == np.float64 else 3e-2
+    for col, key in ((3, 'gnorm'), (2, 'delta')):
+        assert np.allclose([x[key] for x in st], tron[:, col], rtol=loose), key
+    same_cg = cg == g['cg_iter']                                    # a +-1 CG step changes the step itself
+    for col, key in ((0, 'actred'), (1, 'prered')):
+        got = np.array([x[key] for x in st])
+        assert np.all(np.abs(got - tron[:, col])[same_cg] <= loose * np.abs(tron[:, col])[same_cg] + 2e-4 * np.abs(g['f_x'])[same_cg]), key
     if g['missing']:
         J = O.objective(g['Y'], g['lag_set'], model.W, model.H, model.lag_val, g['hyper'])
         assert abs(Jdev - J) / J < 1e-5
+
+
+NOISE_FLOOR_CASES = {('float32', 64, 32)}      # ill-conditioned truncated CG: the fp32 restatement is itself ~1e-3 from the fp64 trajectory
 
 
 @pytest.mark.parametrize('dtype,k,nlag', [(np.float32, 16, 8), (np.float32, 40, 16), (np.float64, 24, 4),
@@ -105,6 +118,8 @@ def test_fresh_seeded_problem_vs_restatement(dtype, k, nlag):
     if direct or dtype == np.float64:
         assert direct
         return
+    # whitelist of the fp32 cases allowed to take the noise-floor route (everything else must pass the direct gates)
+    assert (np.dtype(dtype).name, k, nlag) in NOISE_FLOOR_CASES, 'fp32 case (k=%d, |L|=%d) missed the direct gates' % (k, nlag)
     Y64 = p['Y'].astype(np.float64)
     W64, H64 = m0.W.astype(np.float64), m0.H.astype(np.float64)
     T64 = np.asfortranarray(m0.lag_val.astype(np.float64))
@@ -151,6 +166,28 @@ def test_objective_parity_fp32_10_iterations_config2_shape():
     print('cg oracle', [l['cg_iter'] for l in log], 'cg gpu', [x['cg_iter'] for x in st], 'J', Jo, Jp)
     assert abs(Jp - Jo) / Jo < 1e-5
     assert relfro(model.W, W) < 1e-3 and relfro(model.H, H) < 1e-3
+
+
+def test_fp32_parity_near_convergence_40_iterations():
+    """Far into the run (40 ALS iterations, fp32) the steps are small and the acceptance test of the reference compares
+    two nearly equal objective values (rf_tron.h:191-222) where this build uses the quadratic identity: the iterates must
+    still agree -- objective to 1e-5, factors to the fp32 gate -- and every step must be accepted on both sides."""
+    p = synth.sparse_problem(n=1200, T=500, k=16, nlag=8, density=0.05, dtype=np.float32, seed=5)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], 16, seed=5)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    iters = 40
+    log = O.train_port(p['Y'], p['lag_set'], W, H, Th, synth.HYPER, max_iter=iters, threads=8)
+    model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+    with session.Session(p['Y'], model, missing=True, **synth.HYPER) as s:
+        s.run(iters); st = s.stats(iters); s.download()
+    Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
+    Jp = O.objective(p['Y'], p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
+    print('40 iterations fp32: dJ %.2e relfro W %.2e H %.2e; accepted oracle %d gpu %d; last CG oracle %s gpu %s' % (
+        abs(Jp - Jo) / Jo, relfro(model.W, W), relfro(model.H, H), sum(l['accepted'] for l in log), sum(x['accepted'] for x in st),
+        [l['cg_iter'] for l in log[-5:]], [x['cg_iter'] for x in st[-5:]]))
+    assert all(l['accepted'] == 1 for l in log) and all(x['accepted'] == 1 for x in st)
+    assert abs(Jp - Jo) / Jo < 1e-5
+    assert relfro(model.W, W) < 2e-3 and relfro(model.H, H) < 2e-3
 
 
 @pytest.mark.parametrize('form', ['wave'])
