@@ -61,4 +61,28 @@ __global__ __launch_bounds__(64) void latent_forecast_kernel(real *__restrict__ 
     }
 }
 
+// dst[j][i] = raw[j][i] * a[i] + b[i]: the per-series affine map of NormalizedTransform.preprocess
+// (python/trmf/trmf.py:82-96).  NumPy evaluates `Y * a + b` in the common dtype of Y and the coefficients -- which
+// are fitted from Y and therefore have its dtype -- with the product and the sum rounded separately: val_type
+// arithmetic, no fused multiply-add.  rows x cols row-major; also emits per-workgroup partial sums of dst^2.
+__global__ __launch_bounds__(256) void affine_columns_kernel(const real *__restrict__ raw, size_t rows, int cols,
+                                                             const real *__restrict__ a, const real *__restrict__ b,
+                                                             real *__restrict__ dst, double *__restrict__ Psq) {
+#pragma clang fp contract(off)
+    __shared__ double sm[4];
+    const size_t N = rows * (size_t)cols;
+    double acc = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        const int i = (int)(e % (size_t)cols);
+        const real prod = raw[e] * a[i];
+        const real y = prod + b[i];
+        dst[e] = y;
+        acc += (double)y * (double)y;
+    }
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) Psq[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
 }  // namespace trmf

@@ -46,7 +46,13 @@ template <typename T> struct DevBuf {
         release();
         n = count;
         TRMF_HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
-        if (zero) TRMF_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+        if (zero) {
+            // hipMemset runs on the NULL stream and may return before the fill has executed; the solver's stream is
+            // non-blocking (never ordered against the NULL stream), so the fill must be complete before anyone on that
+            // stream can touch the buffer.  Allocation is set-up work: a device-wide wait is fine here.
+            TRMF_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+            TRMF_HIP_CHECK(hipDeviceSynchronize());
+        }
         return 0;
     }
     int upload(const T *src, size_t count) {
@@ -280,6 +286,42 @@ struct TrmfSessionImpl {
         return 0;
     }
 
+    // ---- per-series affine transform of a resident dense Y (trmf_session_set_series_transform) -------------------------
+    // rolling_validate(transform=True) -- the paper scripts' setting -- refits a NormalizedTransform on every growing
+    // prefix (trmf.py:82-96, 237-249), which rescales EVERY entry of Y.  The session therefore keeps the raw matrix and
+    // re-derives both training orientations from it on the device; only the 2n coefficients cross PCIe per window.
+    DevBuf<real> Yraw;
+    DevBuf<real> tr_a, tr_b;
+    DevBuf<double> tr_part;
+    bool has_transform = false;
+    int set_series_transform(const real *a, const real *b) {
+        if (!dense) { set_error("set_series_transform: needs a dense Y (missing == 0)"); return kFail; }
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        if (Yraw.n != (size_t)T * n) {              // first call: the resident copy is still the raw matrix
+            if (has_transform) { set_error("set_series_transform: raw matrix lost"); return kFail; }
+            if (Yraw.alloc((size_t)T * n, false)) return kFail;
+            TRMF_HIP_CHECK(hipMemcpyAsync(Yraw.p, Yd_tn.p, (size_t)T * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        }
+        std::vector<real> one((size_t)n, real(1)), zero((size_t)n, real(0));
+        if (tr_a.upload(a ? a : one.data(), n) || tr_b.upload(b ? b : zero.data(), n)) return kFail;
+        has_transform = true;
+        return apply_series_transform();
+    }
+    int apply_series_transform() {
+        const int nb = 1024;
+        if (tr_part.alloc(nb)) return kFail;
+        hipLaunchKernelGGL(affine_columns_kernel, dim3(nb), dim3(256), 0, stream, Yraw.p, (size_t)T, n, tr_a.p, tr_b.p, Yd_tn.p, tr_part.p);
+        launch_transpose(Yd_tn.p, T, n, Yd_nt.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        std::vector<double> part(nb);
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        TRMF_HIP_CHECK(hipMemcpy(part.data(), tr_part.p, nb * sizeof(double), hipMemcpyDeviceToHost));
+        ysq_acc = 0;
+        for (double v : part) ysq_acc += v;
+        set_trYTY();
+        return 0;
+    }
+
     // ---- append new timestamps (trmf_session_append_rows; the rolling-window caller trmf.py:303-329) ---------------
     // Ynew: Tn x n block of NEW timestamps, same storage class as the session's Y.  Only that block (plus, for a
     // sparse Y, one 4-byte pointer per item) crosses PCIe: the CSR gains rows at its end, the CSC -- whose columns
@@ -330,6 +372,14 @@ struct TrmfSessionImpl {
             if (tn2.alloc((size_t)T1 * n, false) || nt2.alloc((size_t)T1 * n, false)) return kFail;
             TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p, Yd_tn.p, (size_t)T0 * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
             TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p + (size_t)T0 * n, blk.data(), blk.size() * sizeof(real), hipMemcpyHostToDevice, stream));
+            if (has_transform) {                        // the block is RAW data: grow the raw copy, re-derive below
+                DevBuf<real> raw2;
+                if (raw2.alloc((size_t)T1 * n, false)) return kFail;
+                TRMF_HIP_CHECK(hipMemcpyAsync(raw2.p, Yraw.p, (size_t)T0 * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
+                TRMF_HIP_CHECK(hipMemcpyAsync(raw2.p + (size_t)T0 * n, blk.data(), blk.size() * sizeof(real), hipMemcpyHostToDevice, stream));
+                TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+                Yraw.swap(raw2);
+            }
             launch_transpose(tn2.p, T1, n, nt2.p);
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));
             Yd_tn.swap(tn2); Yd_nt.swap(nt2);
@@ -345,6 +395,7 @@ struct TrmfSessionImpl {
             W.swap(W2);
         }
         T = T1;
+        if (dense && has_transform && apply_series_transform()) return kFail;   // current coefficients over the grown raw matrix
         set_trYTY();
         iter = 0;
         if (gramx_mode != kGramxReplicate && comm->world > 1 && !getenv("TRMF_GRAMX")) { gramx_mode = kGramxMeasure; gramx_calls = 0; }

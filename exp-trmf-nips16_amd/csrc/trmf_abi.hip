@@ -224,6 +224,11 @@ int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew) {
     return guard.ok ? IMPL(s)->append_rows(Ynew) : kFail;
 }
 int32_t trmf_session_rows(TrmfSession *s) { return s ? IMPL(s)->T : kFail; }
+int32_t trmf_session_set_series_transform(TrmfSession *s, const void *a, const void *b) {
+    if (!s) { set_error("null session"); return kFail; }
+    DeviceGuard guard;
+    return guard.ok ? IMPL(s)->set_series_transform((const real *)a, (const real *)b) : kFail;
+}
 
 int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val) {
     if (!s) return kFail;

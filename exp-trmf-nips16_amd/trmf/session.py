@@ -47,6 +47,8 @@ def bind(lib):
     lib.trmf_session_sync.argtypes = [c_void_p]; lib.trmf_session_sync.restype = c_int32
     lib.trmf_session_append_rows.argtypes = [c_void_p, P]; lib.trmf_session_append_rows.restype = c_int32
     lib.trmf_session_rows.argtypes = [c_void_p]; lib.trmf_session_rows.restype = c_int32
+    lib.trmf_session_set_series_transform.argtypes = [c_void_p, c_void_p, c_void_p]
+    lib.trmf_session_set_series_transform.restype = c_int32
     lib.trmf_session_download.argtypes = [c_void_p, P, P, P]; lib.trmf_session_download.restype = c_int32
     lib.trmf_session_stats.argtypes = [c_void_p, POINTER(TrmfIterStats), c_int32]
     lib.trmf_session_stats.restype = c_int32
@@ -106,6 +108,22 @@ class Session(object):
         replaced by a model with ``rows()`` timestamps before the next ``download()``."""
         block = Ynew if isinstance(Ynew, PyMatrix) else PyMatrix(Ynew, dtype=self.model.W.dtype)
         self._check(self.lib.trmf_session_append_rows(self.handle, byref(block)), 'trmf_session_append_rows')
+        return self
+
+    def set_transform(self, transform):
+        """Train on ``transform.preprocess`` of the raw dense Y held by the session (``None``: the raw values); the
+        coefficients (``a``, ``b`` of a ``NormalizedTransform``, which have the dtype of the Y they were fitted on)
+        are applied on the device in the session's element type, as NumPy evaluates ``Y * a + b``."""
+        if transform is None:
+            rc = self.lib.trmf_session_set_series_transform(self.handle, None, None)
+        else:
+            dt = self.model.W.dtype
+            if np.asarray(transform.a).dtype != dt:
+                raise TypeError('transform coefficients are {}, the session trains in {}'.format(np.asarray(transform.a).dtype, dt))
+            a = np.ascontiguousarray(np.asarray(transform.a).ravel())
+            b = np.ascontiguousarray(np.asarray(transform.b, dtype=dt).ravel())
+            rc = self.lib.trmf_session_set_series_transform(self.handle, a.ctypes.data, b.ctypes.data)
+        self._check(rc, 'trmf_session_set_series_transform')
         return self
 
     def rows(self):

@@ -11,8 +11,10 @@ window; on the GPU that would be a fresh upload of everything per window.  ``rol
 HBM-resident session for all windows (``trmf.session.Session``): the first prefix is uploaded once, each later
 window only appends its new timestamps (``Session.append_rows`` -> ``trmf_session_append_rows``: CSR rows
 appended, CSC rebuilt on the device, W extended on the device by the same AR recursion, H and the lag weights
-stay where they are).  A per-window ``NormalizedTransform`` rescales every entry of the prefix, so with a
-transform each window is trained from a fresh upload through ``train`` (``resident=False`` forces that path).
+stay where they are).  A per-window ``NormalizedTransform`` (the paper scripts' ``transform=True``) rescales
+every entry of the prefix: the session then keeps the RAW dense matrix and applies each window's refitted
+coefficients on the device (``Session.set_transform`` -> ``trmf_session_set_series_transform``), so only 2n numbers
+per window are uploaded.  ``resident=False`` forces a fresh upload per window through ``train``.
 """
 import itertools
 import pickle
@@ -29,18 +31,24 @@ def _as_training_matrix(block, missing):
     return smat.csr_matrix(block) if missing else block
 
 
-def _train_windows_resident(Y, lag_set, k, cuts, seed, hyper, max_iter, missing, verbose):
-    """Yield the trained model of every window from one resident session (no transform)."""
+def _train_windows_resident(Y, lag_set, k, cuts, seed, hyper, max_iter, missing, transform, verbose):
+    """Yield the trained model of every window from one resident session.  With a transform (dense Y, full
+    observation) the session holds the RAW matrix and applies each window's refitted coefficients on the device."""
     from .session import Session
-    model = Model.initialize(Y[:cuts[0]], lag_set, k, seed=seed)
+    model = Model.initialize(Y[:cuts[0]], lag_set, k, seed=seed, transform=transform)
     with Session(_as_training_matrix(Y[:cuts[0]], missing), model, missing=missing, verbose=verbose,
                  log_norms=bool(verbose), **hyper) as sess:
+        if model.transform is not None:
+            sess.set_transform(model.transform)
         sess.run(max_iter).download()
         yield model
         for prev_cut, cut in zip(cuts[:-1], cuts[1:]):
-            # host-side model of the new size: same warm start the device applies, same RNG consumption as the reference
-            model = Model.initialize(Y[:cut], lag_set, k, seed=seed, warm_start_model=model)
+            # host-side model of the new size: same warm start the device applies, same RNG consumption as the
+            # reference, and (if asked for) a transform refitted on the grown prefix
+            model = Model.initialize(Y[:cut], lag_set, k, seed=seed, warm_start_model=model, transform=transform)
             sess.append_rows(_as_training_matrix(Y[prev_cut:cut], missing))
+            if model.transform is not None:
+                sess.set_transform(model.transform)
             sess.model = model
             sess.run(max_iter).download()
             yield model
@@ -65,8 +73,9 @@ def rolling_validate(Y, lag_set, k=40, window_size=24, nr_windows=7, lambdaI=0.5
     assert T > horizon, 'series too short for {} windows of {}'.format(nr_windows, window_size)
     cuts = [T - horizon + i * window_size for i in range(nr_windows)]        # training prefix of window i = Y[:cuts[i]]
     hyper = dict(lambdaI=lambdaI, lambdaAR=lambdaAR, lambdaLag=lambdaLag)
-    if resident and transform is None and not smat.issparse(Y):
-        models = _train_windows_resident(Y, lag_set, k, cuts, seed, hyper, max_iter, missing, verbose)
+    # resident: a NumPy Y, and a transform only where the device can apply it (dense full-observation training)
+    if resident and isinstance(Y, np.ndarray) and (transform is None or (not missing and Y.dtype in (np.float32, np.float64))):
+        models = _train_windows_resident(Y, lag_set, k, cuts, seed, hyper, max_iter, missing, transform, verbose)
     else:
         models = _train_windows_fresh(Y, lag_set, k, cuts, seed, hyper, max_iter, missing, transform, threads, verbose)
     forecasts = np.zeros((horizon, n), dtype=Y.dtype, order='C')

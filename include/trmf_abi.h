@@ -155,6 +155,15 @@ TRMF_API int32_t trmf_session_log_norms(TrmfSession *s, int32_t on);
  * restarts at 1 like a fresh c_trmf_train call (period_* gating, trmf.cpp:647).  Blocking.  With a communicator
  * active every rank must call it with the same block. */
 TRMF_API int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew);
+/* Train on a[i] * y + b[i] of series (column) i instead of the raw dense Y the session holds (missing == 0 only):
+ * the per-window NormalizedTransform of the reference's rolling_validate(transform=True) (python/trmf/trmf.py:82-96,
+ * 237-249, 253-257), which rescales every entry of the growing prefix.  The session keeps the raw matrix (rows passed
+ * to create / append_rows are always RAW) and re-derives both training orientations on the device.  The
+ * coefficients are arrays of n values of THIS library's element type (they are fitted from Y and have its dtype);
+ * y * a + b is evaluated in that type with the product and the sum rounded separately, as NumPy evaluates it; only
+ * the 2n coefficients are uploaded.  a == NULL / b == NULL mean 1 / 0.  May be called again at any time (e.g. after
+ * append_rows, with the coefficients refitted on the grown prefix). */
+TRMF_API int32_t trmf_session_set_series_transform(TrmfSession *s, const void *a /* n */, const void *b /* n */);
 /* Number of timestamps currently held by the session (rows of W). */
 TRMF_API int32_t trmf_session_rows(TrmfSession *s);
 /* Block until all enqueued work of the session has finished. */

@@ -148,3 +148,18 @@ def test_cold_start_validates_but_never_writes(capfd):
     err = capfd.readouterr().err
     assert 'Y.rows (30) != W.rows (29)' in err
     assert all(np.array_equal(a, get(m)) for a, m in zip(before, (pyW, pyH, pyT)))
+
+
+def test_rank_one_quirk_q2_is_reproduced(capfd):
+    """a (T, 1) NumPy array is both C- and F-contiguous and PyMatrix tests f_contiguous first, so
+    W and H of a rank-1 model arrive tagged column-major; the reference's dimension check rejects them and returns
+    without touching anything (trmf.cpp:583-586).  Same here, before any device is needed."""
+    import trmf
+    Y = smat.random(25, 12, density=0.4, random_state=np.random.RandomState(1), format='csr', dtype=np.float32)
+    m = trmf.Model.initialize(Y, [1, 2], 1, seed=0)
+    assert m.pyW.type == 2 and m.pyH.type == 2
+    W0, H0 = m.W.copy(), m.H.copy()
+    trmf.train(Y, m, max_iter=2, missing=True)
+    err = capfd.readouterr().err
+    assert 'W should be rowmajored' in err and 'H should be rowmajored' in err
+    assert np.array_equal(m.W, W0) and np.array_equal(m.H, H0)

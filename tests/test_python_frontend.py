@@ -182,3 +182,39 @@ def test_session_append_rows_equals_fresh_session(dtype, missing):
         s.run(3); st_f = s.stats(3); s.download()
     assert [x['cg_iter'] for x in st_g] == [x['cg_iter'] for x in st_f]
     assert np.array_equal(grown2.W, fresh.W) and np.array_equal(grown2.H, fresh.H) and np.array_equal(grown2.lag_val, fresh.lag_val)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_session_series_transform_equals_host_preprocess(dtype):
+    """trmf_session_set_series_transform: a session holding the RAW dense matrix with the per-series affine map applied
+    on the device trains exactly like a fresh session on NormalizedTransform.preprocess(Y) evaluated by NumPy -- also
+    after the raw matrix has grown and the transform has been refitted (the rolling-window flow)."""
+    from helpers import make_model
+    from trmf import session, synth
+    T0, Tn, n, k, lags = 260, 20, 31, 5, [1, 2, 7]
+    d = trmf.Model.syn_gen(T0 + Tn, n, k, lags, seed=4, dtype=np.float64)
+    Y = np.ascontiguousarray(3.0 * d['Y'] + 5.0 + 0.1 * np.random.RandomState(4).randn(T0 + Tn, n), dtype=dtype)
+    hyper = dict(lambdaI=0.5, lambdaAR=125.0, lambdaLag=2.0)
+    m0 = trmf.Model.initialize(Y[:T0], lags, k, seed=1, transform=True)
+    dev = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    with session.Session(Y[:T0], dev, missing=False, **hyper) as s:
+        s.set_transform(m0.transform)
+        s.run(3).download()
+        host = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+        with session.Session(np.ascontiguousarray(m0.transform.preprocess(Y[:T0]).astype(dtype)), host, missing=False, **hyper) as s2:
+            s2.run(3).download()
+        assert np.array_equal(dev.W, host.W) and np.array_equal(dev.H, host.H) and np.array_equal(dev.lag_val, host.lag_val)
+        # grow by a block of RAW rows, refit the transform on the grown prefix
+        first = make_model(dev.W, dev.H, dev.lag_val, dev.lag_set)
+        first.transform = m0.transform                       # a warm start inherits (and refits) the previous model's transform
+        m1 = trmf.Model.initialize(Y, lags, k, seed=1, warm_start_model=first)
+        s.append_rows(Y[T0:])
+        s.set_transform(m1.transform)
+        dev1 = make_model(m1.W, m1.H, m1.lag_val, m1.lag_set)
+        s.model = dev1
+        s.run(3).download()
+    host1 = make_model(m1.W, m1.H, m1.lag_val, m1.lag_set)
+    with session.Session(np.ascontiguousarray(m1.transform.preprocess(Y).astype(dtype)), host1, missing=False, **hyper) as s3:
+        s3.run(3).download()
+    assert np.array_equal(dev1.W, host1.W) and np.array_equal(dev1.H, host1.H) and np.array_equal(dev1.lag_val, host1.lag_val)
