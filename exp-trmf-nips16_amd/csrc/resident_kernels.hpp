@@ -61,6 +61,41 @@ __global__ __launch_bounds__(64) void latent_forecast_kernel(real *__restrict__ 
     }
 }
 
+// Factor layout conversion on the device (the ABI delivers rows x k row-major; HBM holds (rows+1) x KP with the
+// column-interleaved layout of common.hpp, pads and the extra row zero).  One thread per element of the padded table.
+__global__ __launch_bounds__(256) void factor_pad_kernel(const real *__restrict__ src, size_t rows, int k, int KP, int NT,
+                                                         real *__restrict__ dst) {
+    const size_t N = (rows + 1) * (size_t)KP;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / KP;
+        const int t = collog((int)(e - i * KP), NT);
+        dst[e] = (i < rows && t < k) ? src[i * (size_t)k + t] : real(0);
+    }
+}
+__global__ __launch_bounds__(256) void factor_unpad_kernel(const real *__restrict__ src, size_t rows, int k, int KP, int NT,
+                                                           real *__restrict__ dst) {
+    const size_t N = rows * (size_t)k;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / k;
+        const int t = (int)(e - i * k);
+        dst[e] = src[i * (size_t)KP + colpos(t, NT)];
+    }
+}
+// 64-bit row pointers of the ABI narrowed to the 32-bit device form
+__global__ __launch_bounds__(256) void narrow_ptr_kernel(const uint64_t *__restrict__ src, size_t count, uint32_t *__restrict__ dst) {
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (size_t)gridDim.x * 256) dst[e] = (uint32_t)src[e];
+}
+// sum of squares of a value array (fp64, fixed-order per-workgroup partials)
+__global__ __launch_bounds__(256) void sumsq_values_kernel(const real *__restrict__ v, size_t count, double *__restrict__ Psq) {
+    __shared__ double sm[4];
+    double acc = 0;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (size_t)gridDim.x * 256) acc += (double)v[e] * (double)v[e];
+    for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) Psq[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
 // dst[j][i] = raw[j][i] * a[i] + b[i]: the per-series affine map of NormalizedTransform.preprocess
 // (python/trmf/trmf.py:82-96).  NumPy evaluates `Y * a + b` in the common dtype of Y and the coefficients -- which
 // are fitted from Y and therefore have its dtype -- with the product and the sum rounded separately: val_type

@@ -117,24 +117,53 @@ struct TrmfSessionImpl {
     double *P(int slot) { return partials.p + (size_t)slot * xp.pstride; }
 
     // ---------------------------------------------------------------------------------------------
-    // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).
+    // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).  The ABI's rows x k
+    // arrays cross PCIe as they are; padding and column interleaving happen on the device (a host loop took 1.5 s for
+    // the 512 MB item factor of config 5).
     int upload_padded(DevBuf<real> &dst, const real *src, size_t rows) {
-        std::vector<real> tmp((rows + 1) * (size_t)KP, real(0));
-        for (size_t i = 0; i < rows; i++)
-            for (int t = 0; t < k; t++) tmp[i * KP + colpos(t, NT)] = src[i * (size_t)k + t];   // interleaved columns
-        return dst.upload(tmp.data(), tmp.size());
-    }
-    int download_padded(const DevBuf<real> &src, real *dst, size_t rows) {
-        std::vector<real> tmp(rows * (size_t)KP);
-        if (tmp.size()) TRMF_HIP_CHECK(hipMemcpy(tmp.data(), src.p, tmp.size() * sizeof(real), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < rows; i++)
-            for (int t = 0; t < k; t++) dst[i * (size_t)k + t] = tmp[i * KP + colpos(t, NT)];
+        DevBuf<real> raw;
+        if (raw.upload(src, rows * (size_t)k) || dst.alloc((rows + 1) * (size_t)KP, false)) return kFail;
+        const size_t N = (rows + 1) * (size_t)KP;
+        hipLaunchKernelGGL(factor_pad_kernel, dim3((unsigned)std::min<size_t>(4096, (N + 255) / 256)), dim3(256), 0, stream,
+                           raw.p, rows, k, KP, NT, dst.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
-    static int upload_ptr32(DevBuf<uint32_t> &dst, const size_t *src, size_t count) {
-        std::vector<uint32_t> tmp(count);
-        for (size_t i = 0; i < count; i++) tmp[i] = (uint32_t)src[i];
-        return dst.upload(tmp.data(), count);
+    int download_padded(const DevBuf<real> &src, real *dst, size_t rows) {
+        if (rows == 0) return 0;
+        DevBuf<real> raw;
+        const size_t N = rows * (size_t)k;
+        if (raw.alloc(N, false)) return kFail;
+        hipLaunchKernelGGL(factor_unpad_kernel, dim3((unsigned)std::min<size_t>(4096, (N + 255) / 256)), dim3(256), 0, stream,
+                           src.p, rows, k, KP, NT, raw.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        TRMF_HIP_CHECK(hipMemcpy(dst, raw.p, N * sizeof(real), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    int upload_ptr32(DevBuf<uint32_t> &dst, const size_t *src, size_t count) {
+        DevBuf<uint64_t> wide;
+        if (wide.upload((const uint64_t *)src, count) || dst.alloc(count, false)) return kFail;
+        hipLaunchKernelGGL(narrow_ptr_kernel, dim3((unsigned)std::min<size_t>(1024, (count + 255) / 256)), dim3(256), 0, stream, wide.p, count, dst.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    // sum of squares of a device value array, fp64 (fixed order)
+    int device_sum_squares(const real *dv, size_t count, double *out) {
+        const int nb = 1024;
+        DevBuf<double> part;
+        if (part.alloc(nb)) return kFail;
+        hipLaunchKernelGGL(sumsq_values_kernel, dim3(nb), dim3(256), 0, stream, dv, count, part.p);
+        TRMF_HIP_CHECK(hipGetLastError());
+        std::vector<double> h(nb);
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        TRMF_HIP_CHECK(hipMemcpy(h.data(), part.p, nb * sizeof(double), hipMemcpyDeviceToHost));
+        double acc = 0;
+        for (double x : h) acc += x;
+        *out = acc;
+        return 0;
     }
 
     // Host copies of the two pointer arrays (8 bytes per row/column): row partitions, the byte model of
@@ -166,7 +195,7 @@ struct TrmfSessionImpl {
             if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
             if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
             if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
-            ysq_acc = sum_squares((const real *)Y->val_t, nnz);
+            if (device_sum_squares(Yr_val.p, nnz, &ysq_acc)) return kFail;
         } else {
             // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC
             std::vector<real> tn;
@@ -363,8 +392,8 @@ struct TrmfSessionImpl {
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));
             Yr_ptr.swap(ptr2); Yr_idx.swap(idx2); Yr_val.swap(val2);
             Yc_ptr.swap(cptr2); Yc_idx.swap(cidx2); Yc_val.swap(cval2);
-            ysq_acc += sum_squares((const real *)Yn->val_t, nzn);
             nnz = nz1;
+            if (device_sum_squares(Yr_val.p, nnz, &ysq_acc)) return kFail;
         } else {
             std::vector<real> blk;
             ysq_acc += dense_rows_to_rowmajor(Yn, blk);
