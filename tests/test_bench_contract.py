@@ -1,0 +1,32 @@
+"""CPU: pieces of bench.py's contract that need no GPU -- the committed PMC traffic figure belongs to the kernel
+sources in the tree (otherwise bench.py silently drops `roofline.traffic`), the byte model, the CPU-baseline worker."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_traffic_profile_belongs_to_the_current_kernel_sources():
+    import bench
+    tj = json.load(open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')))
+    assert tj['kernel_source_sha256'] == bench.fsolve_source_digest(), \
+        'profiles/fsolve_traffic.json is stale: re-run scripts/pmc_fsolve.sh on a GPU box and scripts/make_traffic_json.py'
+    # byte model of SURVEY.md 8(d) at config 3
+    nnz, n, T, k, s = 9950287, 100000, 10000, 40, 4
+    assert tj['algorithmic_bytes'] == nnz * (4 + s + k * s) + (n + 1) * 8 + n * k * s
+    assert tj['compulsory_bytes'] == nnz * (4 + s) + (n + 1) * 8 + T * k * s + n * k * s
+    assert tj['traffic_bytes'] == round((2 * tj['fetch_size_kb'] + tj['write_size_kb']) * 1024)
+    assert os.path.exists(os.path.join(ROOT, tj['source']))
+
+
+def test_cpu_baseline_worker_protocol():
+    """The child process of bench.py's cpu_baseline: full-iteration time and the F / X / Theta split, one JSON line."""
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--cpu-baseline-worker', 'port', '--config', 'tiny',
+                          '--cpu-iters', '3', '--cpu-threads', '2'], capture_output=True, text=True, timeout=300)
+    line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
+    r = json.loads(line)
+    assert r['iters'] == 3 and r['threads'] == 2
+    assert all(r[key] > 0 for key in ('seconds', 's_per_F', 's_per_X', 's_per_Theta'))
