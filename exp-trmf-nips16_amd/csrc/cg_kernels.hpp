@@ -7,8 +7,7 @@
 // written by the previous kernel, so
 //   * the host enqueues the whole solve without a single synchronisation,
 //   * every workgroup -- and, with several GPUs, every rank -- derives bit-identical scalars,
-//   * a stop is "sticky": once ||r|| <= cgtol, cg_update_kernel only forwards the partials, so all
-//     later (already enqueued) iterations see the same r^T r and do nothing.  The fused path records
+//   * a stop is "sticky": all later (already enqueued) iterations do nothing.  The CG records
 //     the ITERATION INDEX of the stopping launch (XState::stop_it); launch `it` returns early only
 //     when stop_it < it, a value that can only have been written by an EARLIER launch -- the
 //     stopping launch itself always sees "not stopped yet" in every one of its workgroups, whatever
@@ -208,31 +207,56 @@ __device__ __forceinline__ double block_allsum_wide(double v, double *smem /* >=
     __syncthreads();
     return r;
 }
-template <bool FUSE_DIR>
-__global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, const XState *__restrict__ st,
-                                                             const double *__restrict__ Prr_cur,
-                                                             const double *__restrict__ Prr_prev, int np,
-                                                             const real *__restrict__ v, const real *__restrict__ rvec,
-                                                             real *__restrict__ dnew,
+// MODE AR_PLAIN: base = AR/ridge part for the operand v (gradient at w, H s, first CG product).
+// MODE AR_CG_STEP: CG iteration it >= 1 of the unfused path, the counterpart of hv_tile_kernel<HV_CG_STEP>: the three
+//   dot products <d,Hd>, <r,Hd>, <Hd,Hd> of iteration it-1 (per-workgroup partials written by apply_kernel, `np` of
+//   them) give alpha, r^T r of the new residual by the recurrence rho' = rho - 2 alpha <r,Hd> + alpha^2 <Hd,Hd>, the
+//   stop test and beta; the staged rows are updated on the fly (s += alpha d and r' = r - alpha Hd on the own rows,
+//   d' = r' + beta d on every staged row: the halo is recomputed from the previous iteration's buffers, which are
+//   ping-pong so that no workgroup overwrites what a neighbour still reads).  A stop is recorded as the iteration
+//   index (XState::stop_it, see hv_tile_kernel); the stopping launch closes s and r and skips the operator.
+enum ArMode { AR_PLAIN = 0, AR_CG_STEP = 1 };
+struct ArVecs {
+    const real *v;        // PLAIN: operand;  CG_STEP: previous direction d
+    const real *r_in;     // CG_STEP: residual of the previous iteration
+    const real *hd_in;    // CG_STEP: H d of the previous iteration
+    real *s;              // CG_STEP: the step (own rows, in place)
+    real *d_out, *r_out;  // CG_STEP: new direction / residual
+};
+template <int MODE>
+__global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *__restrict__ st, ArVecs a, int np, int it, int last,
                                                              const uint32_t *__restrict__ lag_set,
                                                              const real *__restrict__ theta,
                                                              real *__restrict__ base, double *__restrict__ Pbase, int TI) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ar_smem[];
     __shared__ double smem[32];
+    constexpr bool STEP = MODE == AR_CG_STEP;
     const int tid = threadIdx.x, T = p.T, KP = p.KP, Hh = p.midx, nlag = p.nlag;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
     real *vs = reinterpret_cast<real *>(ar_smem);                                   // vs[row][col]
     double *rs = reinterpret_cast<double *>(ar_smem + (((size_t)rowsV * kArCols * sizeof(real) + 15) / 16 * 16));
     real *ths = reinterpret_cast<real *>(rs + (size_t)rowsR * kArCols);             // ths[l][col]
-    real tmp = 0;
-    if (Prr_cur != nullptr) {
-        double a = 0, b = 0;
-        for (int i = tid; i < np; i += kArThreads) { a += Prr_cur[i]; if (FUSE_DIR) b += Prr_prev[i]; }
-        const real rho = (real)block_allsum_wide(a, smem);
-        if (cg_stopped(rho, st->cgtol)) return;
-        if (FUSE_DIR) {
-            const real rho_prev = (real)block_allsum_wide(b, smem);
-            tmp = rho / rho_prev - (real)1.0;                                        // rf_tron.h:495-497
+    real tmp = 0, alpha = 0, nalpha = 0;
+    bool stopped = false;
+    if (STEP) {
+        if (st->stop_it < it) return;                   // an EARLIER launch ended the CG
+        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
+        double dHd = 0, rHd = 0, HH = 0;
+        for (int i = tid; i < np; i += kArThreads) { dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i]; }
+        dHd = block_allsum_wide(dHd, smem); rHd = block_allsum_wide(rHd, smem); HH = block_allsum_wide(HH, smem);
+        const double rho_prev_d = st->rho_hist[it - 1];
+        const real rho_prev = (real)rho_prev_d;
+        alpha = rho_prev / (real)dHd;                                            // rf_tron.h:460
+        nalpha = -alpha;
+        const double ad = (double)alpha;
+        const double rho_d = fmax(rho_prev_d - 2.0 * ad * rHd + ad * ad * HH, 0.0);   // |r - alpha Hd|^2
+        const real rho = (real)rho_d;
+        stopped = last || cg_stopped(rho, st->cgtol);                            // top of iteration `it`, rf_tron.h:444-446
+        tmp = rho / rho_prev - (real)1.0;                                        // rf_tron.h:495-497
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+            st->rho_hist[it] = rho_d;
+            if (stopped) { st->stop_it = it; st->r_parity = it & 1; }
+            else st->cg_iter = it + 1;
         }
     }
     const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
@@ -240,22 +264,26 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, const XS
         const int l = e / kArCols, cc = e - l * kArCols, t = collog(c0 + cc, p.NT);
         ths[e] = t < p.k ? theta[(size_t)t * nlag + l] : real(0);
     }
-    // (1) operand rows -> LDS (zeros outside [0, T)); own rows of the new direction go out
+    // (1) operand rows -> LDS (zeros outside [0, T)); CG step: s, r, d of the own rows go out
     double vv = 0, ar2 = 0;
     for (int e = tid; e < rowsV * kArCols; e += kArThreads) {
         const int rr = e / kArCols, cc = e - rr * kArCols, i = i0 - Hh + rr;
         real x = 0;
         if (i >= 0 && i < T) {
             const size_t ge = (size_t)i * KP + c0 + cc;
-            x = v[ge];
-            if (FUSE_DIR) { x = fma(tmp, x, x); x = x + rvec[ge]; }
-            if (i >= i0 && i < i1) {
-                if (FUSE_DIR) dnew[ge] = x;
-                vv += (double)x * (double)x;
+            x = a.v[ge];
+            const bool own = i >= i0 && i < i1;
+            if (STEP) {
+                const real rnew = fma(nalpha, a.hd_in[ge], a.r_in[ge]);            // r -= alpha Hd     (rf_tron.h:489-490)
+                if (own) a.s[ge] = fma(alpha, x, a.s[ge]);                         // s += alpha d      (rf_tron.h:461)
+                x = fma(tmp, x, x); x = x + rnew;                                  // d = beta d + r    (rf_tron.h:497-499)
+                if (own) { a.r_out[ge] = rnew; a.d_out[ge] = x; }
             }
+            if (own) vv += (double)x * (double)x;
         }
         vs[e] = x;
     }
+    if (STEP && stopped) return;                        // s and r are final; no further product
     __syncthreads();
     const bool ar_on = nlag > 0 && p.lambdaAR > 0;
     // (2) residuals of rows [i0, i0+TI+midx) (trmf.cpp:110-113 / 136-139): r = x_i - sum_l Theta_l x_{i-L_l}.
@@ -346,9 +374,8 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, const XS
 // otherwise.  The AR + ridge part comes in as `base` (ar_tile_kernel); this kernel adds the cached-Gram product.
 // One thread per (row, column); `rpb` rows per block; the row's v is staged in LDS.
 // dot_mode 0: <out,out>   1: <v,out>
-__global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__restrict__ st,
-                                                    const double *__restrict__ Prr_cur, int np,
-                                                    const real *__restrict__ v,
+__global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__restrict__ st, int cg_it,
+                                                    const real *__restrict__ v, const real *__restrict__ rvec,
                                                     const real *__restrict__ base,
                                                     const real *__restrict__ G,
                                                     const real *__restrict__ Bv, int minus_b,
@@ -358,10 +385,11 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     extern __shared__ __attribute__((aligned(16))) unsigned char apply_smem[];   // k*k reals when the Gram is shared (gstride == 0)
     __shared__ double smem[256];
     __shared__ real vs[256];
-    if (Prr_cur != nullptr) {
-        const real rho = (real)sum_partials(Prr_cur, np, smem);
-        if (cg_stopped(rho, st->cgtol)) return;
-    }
+    // cg_it >= 0: this is H d of CG iteration cg_it (d = v, residual = rvec): nothing to do once the CG has stopped at
+    // or before that iteration (stop_it is written by the ar_tile launch of the iteration, an EARLIER launch); the
+    // partials are then <d,Hd>, <r,Hd>, <Hd,Hd> in the slots P_CG0 + 3 (cg_it & 1) .. + 2 (as hv_tile_kernel emits them)
+    const bool cg = cg_it >= 0;
+    if (cg && st->stop_it <= cg_it) return;
     const int k = p.k, KP = p.KP;
     const bool shared_gram = p.gstride == 0;          // full-observation path: one H^T H for every timestamp
     real *Gs = reinterpret_cast<real *>(apply_smem);
@@ -372,7 +400,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     const int lr = threadIdx.x / k, t = threadIdx.x - lr * k;     // t: logical column
     const int tp = colpos(t, p.NT);                                 // its position in a vector row
     const bool active_lane = lr < rpb;
-    double dot = 0, lq = 0;
+    double dot = 0, lq = 0, rhd = 0, hh = 0;
     // rows [row0, row0 + nrows): all of them, or this rank's block when the Gram product is sharded across GPUs
     // (the partial sums then land in this rank's slot range [slot0, slot0 + gridDim.x) and are all-gathered)
     const int ngroups = (nrows + rpb - 1) / rpb;
@@ -405,7 +433,19 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
             o = (real)((double)o + acc);
             out[(size_t)i * KP + tp] = o;
             dot += (double)(dot_mode ? x : o) * (double)o;
+            if (cg) {
+                rhd += (double)rvec[(size_t)i * KP + tp] * (double)o;        // <r,Hd>
+                hh += (double)o * (double)o;                                 // <Hd,Hd>
+            }
         }
+    }
+    if (cg) {
+        block_allsum3(dot, rhd, hh, smem);
+        if (threadIdx.x == 0) {
+            double *Po = Pdot + (size_t)(P_CG0 - P_DOT + 3 * (cg_it & 1)) * p.pstride + slot0 + blockIdx.x;
+            Po[0] = dot; Po[(size_t)p.pstride] = rhd; Po[2 * (size_t)p.pstride] = hh;
+        }
+        return;
     }
     dot = block_allsum(dot, smem);
     lq = block_allsum(lq, smem);
@@ -589,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             if (p.lambdaI > 0) f += 0.5 * p.lambdaI * (double)(real)vv;      // trmf.cpp:73-75
             if (p.nlag > 0 && p.lambdaAR > 0) f += 0.5 * p.lambdaAR * ar2;   // trmf.cpp:94
             st->f = f; st->fnew = f; st->gnorm = gnorm; st->cgtol = cgtol; st->cg_rnorm = gnorm;
-            st->cg_iter = 0; st->accepted = 0; st->rho_hist[0] = (double)ggr;
+            st->cg_iter = stopped ? 0 : 1;          // iterations the CG is committed to so far (launch `it` raises it to it + 1)
+            st->accepted = 0; st->rho_hist[0] = (double)ggr;
             st->stop_it = stopped ? 0 : kCgRunning; st->r_parity = 0;
         }
     }
@@ -913,8 +954,6 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
     const double gg = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
     const double lq = sum_partials(Pbase + P_LQ * (size_t)p.pstride, np_dot, smem);
     const real ggr = (real)gg;                                               // BLAS dot in val_type
-    // rho[0] = r^T r = g^T g (rf_tron.h:439), published as a one-hot partial array
-    if (threadIdx.x == 0) Pbase[P_RR0 * (size_t)p.pstride + blockIdx.x] = (blockIdx.x == 0) ? (double)ggr : 0.0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // loss = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i): the reference's own formula on the full path
         // (trmf.cpp:189-197); on the observed-entries path the same identity over the cached Grams replaces its
@@ -926,52 +965,17 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
         st->f = f; st->fnew = f; st->gnorm = gnorm;
         st->cgtol = (real)(p.eps_cg * gnorm);                                // rf_tron.h:434
         st->cg_rnorm = gnorm;
-        st->cg_iter = 0;
+        const bool stopped = cg_stopped(ggr, (real)(p.eps_cg * gnorm));
+        st->cg_iter = stopped ? 0 : 1;              // iterations the CG is committed to so far (launch `it` raises it to it + 1)
         st->accepted = 0;
-        st->stop_it = kCgRunning; st->r_parity = 0;
+        st->rho_hist[0] = (double)ggr;                                       // rho[0] = r^T r = g^T g (rf_tron.h:439)
+        st->stop_it = stopped ? 0 : kCgRunning;
+        st->r_parity = 0;
     }
     const size_t N = (size_t)p.T * p.KP;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
         const real gv = g[e];
         s[e] = 0; r[e] = -gv; d[e] = -gv;
-    }
-}
-
-// ---- alpha = rho / <d,Hd>; s += alpha d; r -= alpha Hd; partial <r,r> -> rho[it+1] -----------------
-// (rf_tron.h:456-494).  When the iteration is stopped the partials are forwarded unchanged.
-__global__ __launch_bounds__(256) void cg_update_kernel(XParams p, XState *__restrict__ st,
-                                                        const double *__restrict__ Prr_cur,
-                                                        double *__restrict__ Prr_next,
-                                                        const double *__restrict__ PdHd, int np,
-                                                        int np_dHd, int it,
-                                                        const real *__restrict__ d,
-                                                        const real *__restrict__ Hd,
-                                                        real *__restrict__ s, real *__restrict__ r) {
-    __shared__ double smem[256];
-    double s_rho = 0, s_dHd = 0, s_unused = 0;
-    for (int i = threadIdx.x; i < np; i += 256) s_rho += Prr_cur[i];
-    for (int i = threadIdx.x; i < np_dHd; i += 256) s_dHd += PdHd[i];
-    block_allsum3(s_rho, s_dHd, s_unused, smem);
-    const real rho = (real)s_rho;
-    if (cg_stopped(rho, st->cgtol)) {
-        if (threadIdx.x == 0) Prr_next[blockIdx.x] = Prr_cur[blockIdx.x];
-        return;
-    }
-    const real dHd = (real)s_dHd;
-    const real alpha = rho / dHd;                                            // rf_tron.h:460
-    const real nalpha = -alpha;
-    const size_t N = (size_t)p.T * p.KP;
-    double rr = 0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
-        s[e] = fma(alpha, d[e], s[e]);
-        const real rv = fma(nalpha, Hd[e], r[e]);
-        r[e] = rv;
-        rr += (double)rv * (double)rv;
-    }
-    rr = block_allsum(rr, smem);
-    if (threadIdx.x == 0) {
-        Prr_next[blockIdx.x] = rr;
-        if (blockIdx.x == 0) st->cg_iter = it + 1;      // nobody reads cg_iter during the solve
     }
 }
 

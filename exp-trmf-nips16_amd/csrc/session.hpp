@@ -289,8 +289,8 @@ struct TrmfSessionImpl {
             ar_TI = 512;
             while (ar_TI > 32 && ar_tile_lds_bytes(ar_TI, midx, nlag) > 120 * 1024) ar_TI /= 2;
             const size_t need = ar_tile_lds_bytes(ar_TI, midx, nlag);
-            if (allow_dyn_lds(ar_tile_kernel<true>, need, "AR operator (max lag too large)") ||
-                allow_dyn_lds(ar_tile_kernel<false>, need, "AR operator (max lag too large)"))
+            if (allow_dyn_lds(ar_tile_kernel<AR_PLAIN>, need, "AR operator (max lag too large)") ||
+                allow_dyn_lds(ar_tile_kernel<AR_CG_STEP>, need, "AR operator (max lag too large)"))
                 return kFail;
             nbar = ((T + ar_TI - 1) / ar_TI) * (KP / kArCols);
             if (arbase.alloc(NV)) return kFail;
@@ -737,30 +737,37 @@ struct TrmfSessionImpl {
         cg_shard = t_saved > 2.0 * t_gather;
         if (const char *e = getenv("TRMF_CG")) cg_shard = (e[0] == 's');
     }
-    // Unfused path (long lag sets): out = H*v (or the gradient when minus_b) as ar_residual + apply.
-    // `fuse`: v is the previous direction and the new one is formed on the fly.
-    int hv(const real *v, bool fuse, const real *rvec, real *dnew, const double *Pcur, const double *Pprev,
-           int minus_b, real *out, int dot_mode) {
+    // Unfused path (long lag sets): one operator application = ar_tile_kernel (AR + ridge part -> arbase) followed by
+    // apply_kernel (+ cached-Gram product, dot-product partials).
+    //   cg_it < 0: plain product of `av.v` (gradient at w when minus_b, H s)
+    //   cg_it = 0: first CG product H d0 (d = av.v, residual rvec)
+    //   cg_it >= 1: the whole CG iteration (ar_tile_kernel<AR_CG_STEP> closes iteration cg_it-1 and forms the new
+    //               direction av.d_out / residual av.r_out, apply_kernel multiplies it)
+    int hv(const ArVecs &av, int cg_it, int last, int minus_b, real *out, int dot_mode) {
         XState *st = xstate.p;
         double *Pb = partials.p;
         const dim3 ar_grid((T + ar_TI - 1) / ar_TI, KP / kArCols);
         const size_t ar_lds = ar_tile_lds_bytes(ar_TI, midx, nlag);
-        if (fuse)
-            hipLaunchKernelGGL((ar_tile_kernel<true>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, Pcur, Pprev, nbe,
-                               v, rvec, dnew, lag_set.p, theta.p, arbase.p, Pb, ar_TI);
+        const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
+        if (cg_it >= 1)
+            hipLaunchKernelGGL((ar_tile_kernel<AR_CG_STEP>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, av, ndot, cg_it, last,
+                               lag_set.p, theta.p, arbase.p, Pb, ar_TI);
         else
-            hipLaunchKernelGGL((ar_tile_kernel<false>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, Pcur, Pprev, nbe,
-                               v, rvec, dnew, lag_set.p, theta.p, arbase.p, Pb, ar_TI);
+            hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, av, ndot, 0, 0,
+                               lag_set.p, theta.p, arbase.p, Pb, ar_TI);
+        if (last) return 0;                                              // the closing launch has no product
+        const real *operand = cg_it >= 1 ? av.d_out : av.v;
+        const real *resid = cg_it >= 1 ? av.r_out : av.r_in;
         const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : 0;        // shared Gram staged per workgroup
         if (!cg_shard) {
-            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, Pcur, nbe, fuse ? dnew : v, arbase.p,
+            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
                                Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, 0, T, 0);
             return 0;
         }
         // Gram product on this rank's timestamps only; its rows of `out` and its slots of the partial sums are
         // all-gathered (one grouped round), so every rank continues with identical vectors and scalars
         const int rb = (int)xbounds[comm->rank], re = (int)xbounds[comm->rank + 1];
-        hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), ap_lds, stream, xp, st, Pcur, nbe, fuse ? dnew : v, arbase.p,
+        hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
                            Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, rb, re - rb,
                            comm->rank * apply_slots);
         TRMF_HIP_CHECK(hipGetLastError());
@@ -768,8 +775,12 @@ struct TrmfSessionImpl {
         for (int r = 0; r <= comm->world; r++) poff[r] = (uint64_t)r * apply_slots * sizeof(double);
         if (comm->group_begin()) return kFail;
         int rc = gather_rows(out, xbounds, (size_t)KP * sizeof(real));
-        if (rc == 0) rc = comm->allgatherv(P(P_DOT), poff.data(), stream);
-        if (rc == 0 && minus_b) rc = comm->allgatherv(P(P_LQ), poff.data(), stream);
+        if (cg_it >= 0) {
+            for (int a3 = 0; a3 < 3 && rc == 0; a3++) rc = comm->allgatherv(P(P_CG0 + 3 * (cg_it & 1) + a3), poff.data(), stream);
+        } else {
+            if (rc == 0) rc = comm->allgatherv(P(P_DOT), poff.data(), stream);
+            if (rc == 0 && minus_b) rc = comm->allgatherv(P(P_LQ), poff.data(), stream);
+        }
         if (comm->group_end()) return kFail;
         return rc;
     }
@@ -807,26 +818,26 @@ struct TrmfSessionImpl {
             TRMF_HIP_CHECK(hipGetLastError());
             return 0;
         }
-        if (hv(W.p, false, nullptr, nullptr, nullptr, nullptr, 1, g.p, 0)) return kFail;   // gradient, <g,g>, AR/ridge sums
+        real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
         const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
+        ArVecs av{};
+        av.v = W.p;
+        if (hv(av, -1, 0, 1, g.p, 0)) return kFail;                      // gradient, <g,g>, AR/ridge sums
         hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbar, ndot, g.p,
-                           s.p, r.p, d0.p);
-        real *dcur = d0.p, *dalt = d1.p;
-        for (int it = 0; it < maxcg; it++) {
-            double *Pcur = P(P_RR0 + (it & 1)), *Pnext = P(P_RR0 + ((it + 1) & 1));
-            if (it == 0) {
-                if (hv(dcur, false, nullptr, nullptr, Pcur, nullptr, 0, Hd.p, 1)) return kFail;
-            } else {
-                if (hv(dcur, true, r.p, dalt, Pcur, Pnext /* = rho[it-1] */, 0, Hd.p, 1)) return kFail;
-                std::swap(dcur, dalt);
-            }
-            hipLaunchKernelGGL(cg_update_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pcur, Pnext, P(P_DOT),
-                               nbe, ndot, it, dcur, Hd.p, s.p, r.p);
+                           s.p, rbuf[0], dbuf[0]);                       // f, |g|, cgtol, rho[0]; s = 0, r = d = -g
+        av = ArVecs{};
+        av.v = dbuf[0]; av.r_in = rbuf[0];
+        if (hv(av, 0, 0, 0, hbuf[0], 1)) return kFail;                   // H d0 and its three dot products
+        for (int it = 1; it <= maxcg; it++) {                            // launch `maxcg` only closes the last iteration
+            av.v = dbuf[(it - 1) & 1]; av.r_in = rbuf[(it - 1) & 1]; av.hd_in = hbuf[(it - 1) & 1];
+            av.s = s.p; av.d_out = dbuf[it & 1]; av.r_out = rbuf[it & 1];
+            if (hv(av, it, it == maxcg ? 1 : 0, 0, hbuf[it & 1], 1)) return kFail;
         }
-        double *Pfinal = P(P_RR0 + (maxcg & 1));
-        hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, r.p, r.p, w_new.p, Pb);
-        if (hv(s.p, false, nullptr, nullptr, nullptr, nullptr, 0, Hd.p, 1)) return kFail;  // H s, <s,Hs>
-        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, ndot, Pfinal, w_new.p,
+        hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1], w_new.p, Pb);
+        av = ArVecs{};
+        av.v = s.p;
+        if (hv(av, -1, 0, 0, hbuf[0], 1)) return kFail;                  // H s, <s,Hs>
+        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, ndot, (const double *)nullptr, w_new.p,
                            W.p, log_x, log_n);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;

@@ -38,8 +38,13 @@ def test_one_fsolve_matches_golden_inputs(name):
     assert np.array_equal(m.W, g['W0']) and np.array_equal(m.lag_val, g['Th0'])     # untouched phases
 
 
+@pytest.mark.parametrize('path', ['default', 'unfused'])
 @pytest.mark.parametrize('name', golden_names())
-def test_full_run_matches_golden(name):
+def test_full_run_matches_golden(name, path, monkeypatch):
+    """Every golden case through the default X-solve path and again through the unfused kernels (TRMF_NO_HV_TILE:
+    ar_tile + apply, two launches per CG step) that long lag sets use."""
+    if path == 'unfused':
+        monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
     g = load_golden(name)
     m = run_product(g['Y'], g['lag_set'], g['W0'], g['H0'], g['Th0'], g['hyper'], g['max_iter'], missing=g['missing'])
     tol = TOL[np.dtype(g['dtype']).name]
