@@ -117,77 +117,14 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const real *__restri
     if (threadIdx.x == 0) P[blockIdx.x] = acc;
 }
 
-// ---- AR residual r_it = v_it - sum_l Theta_lt v_{i-L_l,t}  (trmf.cpp:110-113 / 136-139) ------------
-// One thread per (i, t); emits partial sums of r^2 (AR part of fun) and v^2 (ridge part of fun).
-// FUSE_DIR (top of CG iteration it >= 1, rf_tron.h:494-502): the operand is the NEW direction
-//   d_new = d + (beta-1) d + r,  beta = rho_cur / rho_prev,
-// recomputed on the fly wherever the stencil needs it and written once to `dnew` (ping-pong buffer).
-template <bool FUSE_DIR>
-__global__ __launch_bounds__(256) void ar_residual_kernel(XParams p, const XState *__restrict__ st,
-                                                          const double *__restrict__ Prr_cur,
-                                                          const double *__restrict__ Prr_prev,
-                                                          int np, const real *__restrict__ v,
-                                                          const real *__restrict__ rvec,
-                                                          real *__restrict__ dnew,
-                                                          const uint32_t *__restrict__ lag_set,
-                                                          const real *__restrict__ theta,
-                                                          double *__restrict__ rAR,
-                                                          double *__restrict__ Pbase) {
-    __shared__ double smem[256];
-    real tmp = 0;
-    if (Prr_cur != nullptr) {
-        const real rho = (real)sum_partials(Prr_cur, np, smem);
-        if (cg_stopped(rho, st->cgtol)) return;
-        if (FUSE_DIR) {
-            const real rho_prev = (real)sum_partials(Prr_prev, np, smem);
-            const real beta = rho / rho_prev;                                // rf_tron.h:495
-            tmp = beta - (real)1.0;                                          // rf_tron.h:497
-        }
-    }
-    auto operand = [&](size_t e) -> real {
-        real dv = v[e];
-        if (FUSE_DIR) {
-            dv = fma(tmp, dv, dv);                                           // axpy(tmp, d, d)
-            dv = dv + rvec[e];                                               // axpy(1, r, d)
-        }
-        return dv;
-    };
-    const size_t N = (size_t)p.T * p.KP;
-    double ar2 = 0, vv = 0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
-        const int i = (int)(e / p.KP), tp = (int)(e - (size_t)i * p.KP);   // tp: position in the row
-        const int t = collog(tp, p.NT);                                       // logical latent dimension
-        const real x = operand(e);
-        if (FUSE_DIR) dnew[e] = x;
-        vv += (double)x * (double)x;
-        double res = 0;
-        if (t < p.k && i >= p.midx && p.nlag > 0) {
-            res = (double)x;
-            for (int l = 0; l < p.nlag; l++) {
-                const real prod = theta[(size_t)t * p.nlag + l] *
-                                  operand((size_t)(i - (int)lag_set[l]) * p.KP + tp);
-                res -= (double)prod;
-            }
-            ar2 += res * res;
-        }
-        rAR[e] = res;
-    }
-    ar2 = block_allsum(ar2, smem);
-    vv = block_allsum(vv, smem);
-    if (threadIdx.x == 0) {
-        Pbase[P_AR * (size_t)p.pstride + blockIdx.x] = ar2;
-        Pbase[P_VV * (size_t)p.pstride + blockIdx.x] = vv;
-    }
-}
-
 // ---- AR + ridge part of the operator, tiled over (time x column group) in LDS ------------------------------
 // base = lambdaI*v + lambdaAR*AR'(AR(v)) for the unfused path (lag sets whose reach does not fit hv_tile_kernel's
 // whole-row tiles: the paper scripts' lags reach back 191 timestamps).  The AR operator never mixes latent
 // dimensions, so a workgroup owns TI consecutive timestamps of kArCols neighbouring columns: it stages the
 // operand rows [i0-midx, i0+TI+midx) of those columns once (every element of v is read from global memory
 // ~(TI+2 midx)/TI times instead of 2|L|+1 times), forms the residuals of rows [i0, i0+TI+midx) there
-// (the halo is recomputed, not exchanged) and applies the adjoint to its own rows.  Same arithmetic and rounding
-// sequence as ar_residual_kernel + the AR section apply_kernel used to carry (trmf.cpp:99-149).
+// (the halo is recomputed, not exchanged) and applies the adjoint to its own rows.  Arithmetic and rounding
+// sequence of trmf.cpp:99-149 (residual in double, every accumulation into the result rounded to val_type).
 // FUSE_DIR: the operand is the new direction d + (beta-1) d + r (rf_tron.h:494-502), written once for the own rows.
 // Partial sums of r^2 (AR part of fun) and v^2 (ridge part) go to slot blockIdx.y * gridDim.x + blockIdx.x.
 constexpr int kArCols = 8;
@@ -454,7 +391,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
 
 // ---- fused Hessian-vector / gradient kernel, tiled over time in LDS --------------------------------
 // One launch = [direction update (FUSE_DIR)] + AR residual + AR adjoint + cached-Gram product
-// (ar_residual_kernel + apply_kernel above, same arithmetic and rounding sequence).  A workgroup owns
+// (ar_tile_kernel + apply_kernel above, same arithmetic and rounding sequence).  A workgroup owns
 // TI consecutive timestamps: it stages the operand rows [i0-midx, i0+TI+midx) in LDS, forms the AR
 // residuals of rows [i0, i0+TI+midx) there (the halo is recomputed, not exchanged), and multiplies its
 // TI cached Grams.  Used when the halo fits LDS (hv_tile_lds_bytes); otherwise the two-kernel path runs.

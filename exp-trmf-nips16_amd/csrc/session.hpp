@@ -7,7 +7,7 @@
 //   W      T x KP, H  n x KP   (KP = k rounded up to 16, zero padded, row-major)
 //   theta  |L| x k column-major (as the ABI delivers it)
 //   G      T x k x k   cached per-timestamp Gram,  Bv  T x KP rhs,  lossrow  T doubles
-//   CG     g, s, r, d0, d1, Hd, w_new: T x KP each; rAR: T x KP doubles; partial-sum arrays
+//   CG     g, s, r/r1, d0/d1, Hd/Hd1, w_new, arbase: T x KP each; partial-sum arrays
 //
 // With several ranks (one process per GPU) the nnz-heavy kernels (F-solve, X-side Gram, loss) run
 // on this rank's contiguous row block and the results are all-gathered; the CG itself runs
@@ -86,7 +86,7 @@ struct TrmfSessionImpl {
     hipStream_t stream = nullptr;
     DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set;
     DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, r1, d0, d1, Hd, Hd1, w_new;
-    DevBuf<double> rAR, lossrow, partials, theta_part;
+    DevBuf<double> lossrow, partials, theta_part;
     // full-observation path (missing == 0)
     bool full = false, dense = false;
     DevBuf<real> Yd_tn, Yd_nt;                // dense Y as T x n and as n x T (both row-major)
@@ -110,7 +110,7 @@ struct TrmfSessionImpl {
             hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.x1, e.lv1};
             for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
         }
-        for (hipEvent_t ev : {gx0, gx1, gx2}) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2}) if (ev) (void)hipEventDestroy(ev);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -219,10 +219,11 @@ struct TrmfSessionImpl {
             hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
             for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
-        for (hipEvent_t *ev : {&gx0, &gx1, &gx2}) TRMF_HIP_CHECK(hipEventCreate(ev));
+        for (hipEvent_t *ev : {&gx0, &gx1, &gx2, &fs0, &fs1, &fs2}) TRMF_HIP_CHECK(hipEventCreate(ev));
         if (gramx_times.alloc((size_t)2 * comm->world)) return kFail;
-        if (comm->world == 1) gramx_mode = kGramxShard;              // nothing to decide
+        if (comm->world == 1) { gramx_mode = kGramxShard; fs_mode = kShardOn; }     // nothing to decide
         if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
+        if (const char *e = getenv("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
         TRMF_HIP_CHECK(hipDeviceSynchronize());
         return 0;
     }
@@ -261,7 +262,7 @@ struct TrmfSessionImpl {
         const size_t NV = (size_t)T * KP;
         if (full && dense && gemm_part.alloc((size_t)kGemmChunks * (size_t)std::max(T, n) * KP)) return kFail;
         if (G.alloc((full ? 1 : (size_t)T * k * k) + kHvGramPad) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
-            d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || r1.alloc(NV) || Hd1.alloc(NV) || w_new.alloc(NV) || rAR.alloc(NV) ||
+            d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || r1.alloc(NV) || Hd1.alloc(NV) || w_new.alloc(NV) ||
             lossrow.alloc(T))
             return kFail;
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
@@ -495,48 +496,76 @@ struct TrmfSessionImpl {
     hipEvent_t gx0 = nullptr, gx1 = nullptr, gx2 = nullptr;
     DevBuf<double> gramx_times;
     int dbg_flags = 0;           // TRMF_DEBUG_ABLATE: bit0 skip Gram, bit1 skip factorisation, bit2 skip back-solve
-    int fsolve(PhaseEvents &ev) {
-        const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
-        TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
-        if (use_quad) {
-            switch (KMAX) {
-                case 8:  launch_fsolve_quad<1, 8>(rb, re); break;
-                case 16: launch_fsolve_quad<1, 16>(rb, re); break;
-                case 24: launch_fsolve_quad<2, 24>(rb, re); break;
-                case 32: launch_fsolve_quad<2, 32>(rb, re); break;
-                case 40: launch_fsolve_quad<3, 40>(rb, re); break;
-                case 48: launch_fsolve_quad<3, 48>(rb, re); break;
-                case 56: launch_fsolve_quad<4, 56>(rb, re); break;
-                case 64: launch_fsolve_quad<4, 64>(rb, re); break;
-                default: set_error("unsupported rank"); return kFail;
-            }
-        } else if (use_grid) {
-            switch (KMAX) {
-                case 8:  launch_fsolve_grid<1, 8>(rb, re); break;
-                case 16: launch_fsolve_grid<1, 16>(rb, re); break;
-                case 24: launch_fsolve_grid<2, 24>(rb, re); break;
-                case 32: launch_fsolve_grid<2, 32>(rb, re); break;
-                case 40: launch_fsolve_grid<3, 40>(rb, re); break;
-                case 48: launch_fsolve_grid<3, 48>(rb, re); break;
-                case 56: launch_fsolve_grid<4, 56>(rb, re); break;
-                case 64: launch_fsolve_grid<4, 64>(rb, re); break;
-                default: set_error("unsupported rank"); return kFail;
-            }
-        } else
-        switch (KMAX) {
-            case 8:  launch_fsolve<1, 8>(rb, re); break;
-            case 16: launch_fsolve<1, 16>(rb, re); break;
-            case 24: launch_fsolve<2, 24>(rb, re); break;
-            case 32: launch_fsolve<2, 32>(rb, re); break;
-            case 40: launch_fsolve<3, 40>(rb, re); break;
-            case 48: launch_fsolve<3, 48>(rb, re); break;
-            case 56: launch_fsolve<4, 56>(rb, re); break;
-            case 64: launch_fsolve<4, 64>(rb, re); break;
-            default: set_error("unsupported rank"); return kFail;
+    int launch_fsolve_rows(uint32_t rb, uint32_t re) {
+#define TRMF_FSOLVE_SWITCH(FN)                                                       \
+        switch (KMAX) {                                                              \
+            case 8:  FN<1, 8>(rb, re); break;                                        \
+            case 16: FN<1, 16>(rb, re); break;                                       \
+            case 24: FN<2, 24>(rb, re); break;                                       \
+            case 32: FN<2, 32>(rb, re); break;                                       \
+            case 40: FN<3, 40>(rb, re); break;                                       \
+            case 48: FN<3, 48>(rb, re); break;                                       \
+            case 56: FN<4, 56>(rb, re); break;                                       \
+            case 64: FN<4, 64>(rb, re); break;                                       \
+            default: set_error("unsupported rank"); return kFail;                    \
         }
+        if (use_quad) { TRMF_FSOLVE_SWITCH(launch_fsolve_quad) }
+        else if (use_grid) { TRMF_FSOLVE_SWITCH(launch_fsolve_grid) }
+        else { TRMF_FSOLVE_SWITCH(launch_fsolve) }
+#undef TRMF_FSOLVE_SWITCH
+        return 0;
+    }
+    // Sharding a phase over the ranks pays only when the all-gather of its result costs less than the rows a rank no
+    // longer computes (true for the F-solve at config 3 on 4 and 8 GPUs, not on 2).  Measure-once rule, shared by the
+    // F-solve and the X-side Gram build: the first call runs sharded and is timed on every rank (kernel, gather); the
+    // times are exchanged through the communicator and every rank takes the same decision.
+    enum { kShardMeasure = 0, kShardOn = 1, kShardOff = 2 };
+    int decide_shard(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, const char *what) {
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        float tk = 0, tg = 0;
+        TRMF_HIP_CHECK(hipEventElapsedTime(&tk, e0, e1));
+        TRMF_HIP_CHECK(hipEventElapsedTime(&tg, e1, e2));
+        const double mine[2] = {(double)tk, (double)tg};
+        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 2 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
+        std::vector<uint64_t> off(comm->world + 1);
+        for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * sizeof mine;
+        if (comm->allgatherv(gramx_times.p, off.data(), stream)) return -1;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<double> all((size_t)2 * comm->world);
+        TRMF_HIP_CHECK(hipMemcpy(all.data(), gramx_times.p, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double t_all_rows = 0, t_sharded = 0;
+        for (int r = 0; r < comm->world; r++) {
+            t_all_rows += all[2 * r];                                        // one GPU doing every rank's rows
+            t_sharded = std::max(t_sharded, all[2 * r] + all[2 * r + 1]);    // slowest rank: its rows + the gather
+        }
+        const int mode = (t_all_rows < 0.95 * t_sharded) ? kShardOff : kShardOn;
+        if (verbose && comm->rank == 0)
+            fprintf(stderr, ">> %s: all rows %.3f ms vs sharded %.3f ms -> %s\n", what, t_all_rows, t_sharded,
+                    mode == kShardOff ? "replicated" : "sharded");
+        return mode;
+    }
+    int fs_mode = kShardMeasure, fs_calls = 0;
+    hipEvent_t fs0 = nullptr, fs1 = nullptr, fs2 = nullptr;
+    int fsolve(PhaseEvents &ev) {
+        if (fs_mode == kShardMeasure && fs_calls == 1) {
+            const int m = decide_shard(fs0, fs1, fs2, "F-solve");
+            if (m < 0) return kFail;
+            fs_mode = m;
+        }
+        const bool replicate = fs_mode == kShardOff, measure = fs_mode == kShardMeasure;
+        const uint32_t rb = replicate ? 0u : (uint32_t)fbounds[comm->rank];
+        const uint32_t re = replicate ? (uint32_t)n : (uint32_t)fbounds[comm->rank + 1];
+        if (measure) TRMF_HIP_CHECK(hipEventRecord(fs0, stream));
+        TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        if (launch_fsolve_rows(rb, re)) return kFail;
         TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
         TRMF_HIP_CHECK(hipGetLastError());
-        return gather_rows(H.p, fbounds, (size_t)KP * sizeof(real));
+        fs_calls++;
+        if (replicate) return 0;                                    // every rank solved every row: nothing to gather
+        if (measure) TRMF_HIP_CHECK(hipEventRecord(fs1, stream));
+        if (gather_rows(H.p, fbounds, (size_t)KP * sizeof(real))) return kFail;
+        if (measure) TRMF_HIP_CHECK(hipEventRecord(fs2, stream));
+        return 0;
     }
 
     // ---- X-side Gram cache / loss ---------------------------------------------------------------------
@@ -581,27 +610,9 @@ struct TrmfSessionImpl {
     // One-time decision after the first (measured, sharded) build.  Rank r publishes (kernel ms, gather ms);
     // after the exchange every rank evaluates the same rule on the same numbers.
     int gramx_decide() {
-        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        float tk = 0, tg = 0;
-        TRMF_HIP_CHECK(hipEventElapsedTime(&tk, gx0, gx1));
-        TRMF_HIP_CHECK(hipEventElapsedTime(&tg, gx1, gx2));
-        const double mine[2] = {(double)tk, (double)tg};
-        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 2 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
-        std::vector<uint64_t> off(comm->world + 1);
-        for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * sizeof mine;
-        if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
-        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<double> all((size_t)2 * comm->world);
-        TRMF_HIP_CHECK(hipMemcpy(all.data(), gramx_times.p, all.size() * sizeof(double), hipMemcpyDeviceToHost));
-        double t_all_rows = 0, t_sharded = 0;
-        for (int r = 0; r < comm->world; r++) {
-            t_all_rows += all[2 * r];                                        // one GPU doing every rank's rows
-            t_sharded = std::max(t_sharded, all[2 * r] + all[2 * r + 1]);    // slowest rank: its rows + the gather
-        }
-        gramx_mode = (t_all_rows < 0.95 * t_sharded) ? kGramxReplicate : kGramxShard;
-        if (verbose && comm->rank == 0)
-            fprintf(stderr, ">> X-side Gram build: all rows %.3f ms vs sharded %.3f ms -> %s\n", t_all_rows, t_sharded,
-                    gramx_mode == kGramxReplicate ? "replicated" : "sharded");
+        const int m = decide_shard(gx0, gx1, gx2, "X-side Gram build");
+        if (m < 0) return kFail;
+        gramx_mode = m == kShardOff ? kGramxReplicate : kGramxShard;
         return 0;
     }
     int loss(const real *Wv, bool all_rows) {
@@ -974,12 +985,16 @@ struct TrmfSessionImpl {
         if (loss(W.p, true)) return NAN;
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, lossrow.p, T, &st->loss1);
         const double l = host_double(&st->loss1);
-        hipLaunchKernelGGL((ar_residual_kernel<false>), dim3(nbe), dim3(256), 0, stream, xp, st,
-                           (const double *)nullptr, (const double *)nullptr, 0, W.p, (const real *)nullptr,
-                           (real *)nullptr, lag_set.p, theta.p, rAR.p, partials.p);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_AR), nbe, &st->gs);
+        {   // AR and ridge sums of W: the AR tile kernel's partials (its operator output goes to scratch)
+            ArVecs av{};
+            av.v = W.p;
+            hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), dim3((T + ar_TI - 1) / ar_TI, KP / kArCols), dim3(kArThreads),
+                               ar_tile_lds_bytes(ar_TI, midx, nlag), stream, xp, st, av, 0, 0, 0, lag_set.p, theta.p, arbase.p,
+                               partials.p, ar_TI);
+        }
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_AR), nbar, &st->gs);
         const double ar = host_double(&st->gs);
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_VV), nbe, &st->gs);
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_VV), nbar, &st->gs);
         const double w2 = host_double(&st->gs);
         log_norm(H.p, (size_t)n * KP, &st->gs);
         const double h2 = host_double(&st->gs);
@@ -987,7 +1002,9 @@ struct TrmfSessionImpl {
     }
 
     // algorithmic bytes of one F-solve launch on this rank
-    double fsolve_bytes() const { return bytes_for_rows(fbounds[comm->rank], fbounds[comm->rank + 1]); }
+    double fsolve_bytes() const {
+        return fs_mode == kShardOff ? bytes_for_rows(0, (uint64_t)n) : bytes_for_rows(fbounds[comm->rank], fbounds[comm->rank + 1]);
+    }
     double bytes_for_rows(uint64_t rb, uint64_t re) const {
         const double sz = sizeof(real);
         const double nz = host_col_ptr.empty() ? 0.0 : (double)(host_col_ptr[re] - host_col_ptr[rb]);
