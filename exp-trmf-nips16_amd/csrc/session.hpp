@@ -865,7 +865,7 @@ struct TrmfSessionImpl {
     }
 
     // ---- Theta solve (trmf.cpp:677-689 -> 455-484) ------------------------------------------------------
-    size_t theta_gram_lds() const { return (size_t)(kThetaChunk + midx) * sizeof(real); }
+    size_t theta_gram_lds() const { return theta_gram_lds_bytes(midx); }
     size_t theta_solve_lds() const { return (size_t)(nlag * nlag + nlag) * sizeof(real); }
     int theta_solve() {
         if (nlag == 0) return 0;
@@ -875,7 +875,7 @@ struct TrmfSessionImpl {
         hipLaunchKernelGGL(theta_gram_kernel, dim3(k, nchunk), dim3(256), lds1, stream, W.p, T, KP, lag_set.p,
                            nlag, midx, npairs, theta_part.p);
         const size_t lds2 = theta_solve_lds();
-        hipLaunchKernelGGL(theta_solve_kernel, dim3(k), dim3(64), lds2, stream, theta_part.p, nchunk, nlag,
+        hipLaunchKernelGGL(theta_solve_kernel, dim3(k), dim3(256), lds2, stream, theta_part.p, nchunk, nlag,
                            npairs, lambdaLag, theta.p);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
