@@ -169,6 +169,11 @@ def test_objective_parity_fp32_10_iterations_config2_shape():
     Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
     Jp = O.objective(p['Y'], p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
     print('cg oracle', [l['cg_iter'] for l in log], 'cg gpu', [x['cg_iter'] for x in st], 'J', Jo, Jp)
+    # the X sub-problem's objective at every iteration (the `f` of the TRON line, here from the cached-Gram identity
+    # instead of a pass over the residuals) against the restatement's full-precision value, not its 4 printed digits
+    f_o, f_p = np.array([l['f'] for l in log]), np.array([x['f'] for x in st])
+    print('max rel dev of f(X sub-problem): %.2e' % np.max(np.abs(f_p - f_o) / f_o))
+    assert np.allclose(f_p, f_o, rtol=1e-5)
     assert abs(Jp - Jo) / Jo < 1e-5
     assert relfro(model.W, W) < 1e-3 and relfro(model.H, H) < 1e-3
 
