@@ -1,0 +1,59 @@
+"""GPU (-m gpu): seeded random small problems across the shapes the kernels specialise on -- every rank class
+(k = 2..64 covers all NT / KMAX instantiations), short and long lag sets (lag 0 included, reach up to T/2), very few items
+or timestamps, empty rows and columns, both precisions, observed-entries and full-observation training (dense C / F
+order and sparse) -- two ALS iterations against the C restatement at the SURVEY.md 8(d) gates."""
+import numpy as np
+import pytest
+import scipy.sparse as smat
+
+import oracle_py as O
+import trmf
+from helpers import TOL, make_model, relfro
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.RandomState(1000 + seed)
+    dtype = [np.float32, np.float64][seed % 2]
+    k = int(rng.choice([2, 3, 5, 8, 9, 16, 17, 24, 31, 32, 33, 40, 41, 47, 48, 49, 56, 57, 63, 64]))
+    nlag = int(rng.choice([1, 2, 3, 5, 8, 13, 24]))
+    T = int(rng.randint(40, 500))
+    reach = int(rng.randint(nlag, max(nlag + 1, T // 2)))
+    lags = np.sort(rng.choice(np.arange(0 if seed % 5 == 0 else 1, reach + 1), size=min(nlag, reach), replace=False))
+    n = int(rng.choice([2, 3, 4, 5, 17, 64, 150, 333]))       # n = 1 is the reference's quirk Q2 (row vector tagged column-major): a no-op
+    missing = seed % 3 != 0
+    hyper = dict(lambdaI=float(rng.choice([0.1, 0.5, 1.0, 2.0])), lambdaAR=float(rng.choice([0.5, 50.0, 625.0])),
+                 lambdaLag=float(rng.choice([0.5, 2.0])))
+    d = trmf.Model.syn_gen(T, n, min(k, 8), [1, 2], seed=seed, dtype=np.float64)
+    Yd = d['Y'] + 0.05 * rng.randn(T, n)
+    if missing:
+        mask = rng.rand(T, n) < rng.choice([0.05, 0.3, 0.9])
+        mask[rng.randint(T)] = False                     # an empty timestamp
+        if n > 2:
+            mask[:, rng.randint(n)] = False              # an empty item
+        Y = smat.csr_matrix(np.where(mask, Yd, 0.0).astype(dtype))
+        Y.eliminate_zeros()
+    else:
+        kind = seed % 4
+        Y = np.asfortranarray(Yd.astype(dtype)) if kind == 0 else np.ascontiguousarray(Yd.astype(dtype))
+        if kind == 1:
+            Y = smat.csr_matrix(np.where(rng.rand(T, n) < 0.4, Y, 0).astype(dtype))
+    return dtype, k, lags.astype(np.uint32), Y, missing, hyper
+
+
+@pytest.mark.parametrize('seed', range(36))
+def test_random_shapes_vs_restatement(seed):
+    dtype, k, lags, Y, missing, hyper = _case(seed)
+    m0 = trmf.Model.initialize(Y, lags, k, seed=seed, dtype=dtype)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    log = O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=2, missing=missing, threads=4)
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    trmf.train(Y, model, max_iter=2, missing=missing, **hyper)
+    tol = TOL[np.dtype(dtype).name]
+    fac = tol['factor'] if dtype == np.float64 else 5 * tol['factor']       # tiny, ill-conditioned fp32 systems: 5e-3
+    what = 'seed %d: %s k=%d lags=%s T=%d n=%d missing=%s %s' % (seed, np.dtype(dtype).name, k, lags.tolist(), Y.shape[0], Y.shape[1],
+                                                              missing, 'sparse' if smat.issparse(Y) else 'dense')
+    print(what, '| relfro W %.1e H %.1e Th %.1e' % (relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th)))
+    assert np.all(np.isfinite(model.W)) and np.all(np.isfinite(model.H)) and np.all(np.isfinite(model.lag_val)), what
+    assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac, what
