@@ -186,6 +186,14 @@ int32_t trmf_set_device(int32_t device) {
     return hipSetDevice(device) == hipSuccess ? 0 : kFail;
 }
 
+int64_t trmf_device_free_bytes(void) {
+    DeviceGuard guard;
+    if (!guard.ok) return -1;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return -1;
+    return (int64_t)free_b;
+}
+
 const char *trmf_last_error(void) {
     static thread_local std::string copy;
     std::lock_guard<std::mutex> lk(g_err_mu);

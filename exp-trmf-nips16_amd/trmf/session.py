@@ -39,6 +39,7 @@ def bind(lib):
     lib.trmf_device_count.restype = c_int32
     lib.trmf_set_device.argtypes = [c_int32]; lib.trmf_set_device.restype = c_int32
     lib.trmf_last_error.restype = c_char_p
+    lib.trmf_device_free_bytes.restype = ctypes.c_int64
     lib.trmf_session_create.argtypes = [P, POINTER(c_uint32), c_uint32, P, P, P, c_double, c_double, c_double,
                                         c_int32, c_int32, c_int32, c_int32, c_int32]
     lib.trmf_session_create.restype = c_void_p

@@ -113,6 +113,8 @@ TRMF_API int32_t trmf_sizeof_real(void);
 TRMF_API int32_t trmf_device_count(void);
 /* Select the HIP device used by subsequent calls from this process (default 0). 0 on success. */
 TRMF_API int32_t trmf_set_device(int32_t device);
+/* Free bytes of HBM on the selected device right now (-1 if no device): sizing aid, and what the leak test reads. */
+TRMF_API int64_t trmf_device_free_bytes(void);
 /* Last error text of section-2 calls (static storage, never NULL). */
 TRMF_API const char *trmf_last_error(void);
 

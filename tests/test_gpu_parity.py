@@ -310,3 +310,28 @@ def test_rolling_validate_harness_on_gpu_matches_oracle_harness():
     want = trmf.Metrics.generate(trueY, forecastY)
     for field in want._fields:
         assert abs(getattr(got, field) - getattr(want, field)) <= 1e-6 * abs(getattr(want, field)) + 1e-9, field
+
+
+def test_sessions_release_their_device_memory():
+    """Create / run / append / destroy 30 sessions (sparse and dense, both libraries): the device's free memory must come
+    back (buffers, streams and events are owned by the session), and one-shot c_trmf_train calls must not leak either."""
+    p = synth.sparse_problem(n=3000, T=800, k=24, nlag=6, density=0.05, dtype=np.float32, seed=3)
+    Yd = np.ascontiguousarray(np.random.RandomState(0).rand(400, 90))
+    lib = session.lib_for(np.float32)
+
+    def cycle():
+        for dtype in (np.float32, np.float64):
+            m = synth.initial_model(p['Y'].astype(dtype)[:700], p['lag_set'], 24, seed=0)
+            with session.Session(p['Y'].astype(dtype)[:700], m, missing=True, **synth.HYPER) as s:
+                s.run(2); s.append_rows(p['Y'].astype(dtype)[700:]); s.model = synth.initial_model(p['Y'].astype(dtype), p['lag_set'], 24, seed=0)
+                s.run(1).download()
+            md = trmf.Model.initialize(Yd.astype(dtype), [1, 2, 30], 7, seed=0)
+            trmf.train(Yd.astype(dtype), md, max_iter=2, missing=False, **synth.HYPER)
+
+    cycle()                                             # warm-up: module loads, allocator pools
+    before = lib.trmf_device_free_bytes()
+    for _ in range(15):
+        cycle()
+    after = lib.trmf_device_free_bytes()
+    assert before > 0 and after > 0
+    assert before - after < 64 << 20, 'free device memory shrank by %.1f MB over 30 sessions' % ((before - after) / 2 ** 20)
