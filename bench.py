@@ -8,7 +8,7 @@ over the synthetic config-3 problem (100k x 10k, 1% dense, k=40, |L|=16, fp32, S
 with Y and the factors already resident in HBM when the timed region starts.  For N > 1 the driver
 launches this file under torch.distributed.run, one rank per GPU; the item rows of the F-solve and
 the timestamp rows of the X-side Gram build are partitioned across ranks inside the library (RCCL
-all-gathers over xGMI), so total work is fixed: "scaling": "strong".
+all-gathers over xGMI; DESIGN.md section 6), so total work is fixed: "scaling": "strong".
 
 Rank 0 prints ONE JSON line.  `roofline` describes the F-solve kernel (HBM-bound under the
 gather-inclusive algorithmic byte model B_F of SURVEY.md 8(d) / BASELINE.md section 3), timed with HIP
@@ -269,7 +269,7 @@ def main():
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
                 args.config, cfg['n'], cfg['T'], cfg.get('density', 1.0), nnz, cfg['k'], len(prob['lag_set']), dtype.name,
                 int(missing), hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
-                'parallelism': 'F rows / X-Gram rows sharded x{}, X-Gram build replicated instead when its all-gather costs more than it saves (decided once, after the first measured iteration), CG replicated'.format(world)},
+                'parallelism': 'item rows of the F-solve and timestamp rows of the X-side Gram build sharded x{} with RCCL all-gathers, each replicated instead when its all-gather costs more than it saves (decided once, from the first measured iteration); fused CG replicated (long-lag / large-T problems: cached-Gram product sharded, H d all-gathered per step)'.format(world)},
             'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_grid_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
