@@ -13,6 +13,8 @@ cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o c3 -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/trace.log 2>&1
 python $R/scripts/stats_table.py $O/trace > $O/kernel_stats.txt 2>&1; head -30 $O/kernel_stats.txt
 bash $R/scripts/pmc_fsolve.sh $TAG/pmc > $O/pmc_fsolve.txt 2>&1; tail -45 $O/pmc_fsolve.txt
+bash $R/scripts/pmc_kernel.sh $TAG/pmc_gramx "gram_x_kernel" > $O/pmc_gram_x.txt 2>&1; tail -22 $O/pmc_gram_x.txt
+bash $R/scripts/pmc_kernel.sh $TAG/pmc_hv "hv_tile_kernel" > $O/pmc_hv_tile.txt 2>&1; tail -22 $O/pmc_hv_tile.txt
 for C in WRITE_SIZE FETCH_SIZE; do
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/wcal_$C -o w -- $R/scripts/ubench/write_calib > $O/wcal_$C.log 2>&1
 done

@@ -7,7 +7,8 @@ mkdir -p $R/gpurun_out/$OUT
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
          "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM_RD" \
-         "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ" "FETCH_SIZE" "TCC_HIT TCC_MISS"; do
+         "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
+         "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$RE" --output-format csv -d $R/gpurun_out/$OUT/p$i -o pmc -- python $R/bench.py --no-cpu-baseline --steps 4 --warmup 1 > $R/gpurun_out/$OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
