@@ -57,3 +57,25 @@ def test_random_shapes_vs_restatement(seed):
     print(what, '| relfro W %.1e H %.1e Th %.1e' % (relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th)))
     assert np.all(np.isfinite(model.W)) and np.all(np.isfinite(model.H)) and np.all(np.isfinite(model.lag_val)), what
     assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac, what
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_random_period_gating_vs_restatement(seed):
+    """period_W / period_H / period_Lag other than (1, 1, 2): a phase runs when iter % period == 0 with iter starting at 1
+    (trmf.cpp:647-693) -- a period above max_iter switches the phase off.  Five iterations against the restatement."""
+    rng = np.random.RandomState(500 + seed)
+    dtype = [np.float64, np.float32][seed % 2]
+    periods = tuple(int(x) for x in rng.choice([1, 2, 3, 7], size=3))
+    Y = smat.random(180, 70, density=0.25, random_state=rng, format='csr', dtype=np.float64).astype(dtype)
+    lags = [1, 2, 5]
+    m0 = trmf.Model.initialize(Y, lags, 12, seed=seed, dtype=dtype)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    hyper = dict(lambdaI=0.5, lambdaAR=50.0, lambdaLag=0.5)
+    O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=5, periods=periods, threads=2)
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    trmf.train(Y, model, max_iter=5, period_W=periods[0], period_H=periods[1], period_Lag=periods[2], missing=True, **hyper)
+    fac = TOL[np.dtype(dtype).name]['factor'] * (1 if dtype == np.float64 else 5)
+    assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac, periods
+    if periods[0] > 5: assert np.array_equal(model.W, m0.W)
+    if periods[1] > 5: assert np.array_equal(model.H, m0.H)
+    if periods[2] > 5: assert np.array_equal(model.lag_val, m0.lag_val)
