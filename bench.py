@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, 'exp-trmf-nips16_amd'))
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+kParityIters = 2            # iterations of the GPU-vs-CPU parity figure carried by the cpu_baseline leg
 
 
 def physical_cores():
@@ -70,7 +71,7 @@ def fsolve_source_digest():
     return h.hexdigest()
 
 
-def cpu_baseline_worker(config, iters, kind, threads, state_file):
+def cpu_baseline_worker(config, iters, kind, threads, state_file, gpu_file=''):
     """Child process: the CPU path on `threads` OpenMP threads, warm-started from the state the GPU's timed window
     started from (state_file: W, H, Theta after the GPU's warm-up iterations).  Protocol of BASELINE.md section 3:
     2 warm-up iterations (also from that state, discarded), then `iters` timed full ALS iterations, wall clock around
@@ -98,13 +99,33 @@ def cpu_baseline_worker(config, iters, kind, threads, state_file):
         run(prob['Y'], prob['lag_set'], W, H, Th, hyper, max_iter=n_iter, periods=periods, threads=threads, missing=missing)
         return time.perf_counter() - t0
 
+    def relfro(a, b):
+        a, b = a.astype(np.float64), b.astype(np.float64)
+        return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
     timed(2, (1, 1, 2))                                            # warm-up: page in, spin up the thread pool
     full = timed(iters, (1, 1, 2))
+    parity = None
+    if gpu_file and os.path.exists(gpu_file) and missing:
+        # the GPU ran the same kParityIters iterations from the same state (bench.py main): objective of both results by
+        # the oracle's fp64 evaluator, and the distance of the factors.  Two iterations, not ten: in fp32 the truncated
+        # CG amplifies rounding differences from iteration to iteration -- at config 3 the reference's own fp32 build is
+        # 1.5e-4 (objective) / 2.7e-3 (W) away from its line-by-line restatement after ten iterations, and both are
+        # 5e-4 / 2e-2 away from the fp64 run (profiles/r02_fp32_trajectory_c3.txt) -- so only a short horizon measures
+        # the implementation rather than the noise floor of the problem
+        g = np.load(gpu_file)
+        W, H, Th = W0.copy(), H0.copy(), np.asfortranarray(T0.copy())
+        run(prob['Y'], prob['lag_set'], W, H, Th, hyper, max_iter=kParityIters, periods=(1, 1, 2), threads=threads, missing=missing)
+        Jc = O.objective(prob['Y'], prob['lag_set'], W, H, Th, hyper)
+        Jg = O.objective(prob['Y'], prob['lag_set'], g['W'], g['H'], g['lag_val'], hyper)
+        parity = {'iters': kParityIters, 'J_cpu': Jc, 'J_gpu': Jg, 'rel_diff': abs(Jg - Jc) / abs(Jc),
+                  'relfro_W': relfro(g['W'], W), 'relfro_H': relfro(g['H'], H), 'relfro_Theta': relfro(g['lag_val'], Th)}
     split_calls = 2
     t_f = timed(split_calls, (big, 1, big)) / split_calls          # (period_W, period_H, period_Lag)
     t_x = timed(split_calls, (1, big, big)) / split_calls
     t_l = timed(split_calls, (big, big, 1)) / split_calls
-    print(json.dumps({'seconds': full, 'iters': iters, 'threads': threads, 's_per_F': t_f, 's_per_X': t_x, 's_per_Theta': t_l}))
+    print(json.dumps({'seconds': full, 'iters': iters, 'threads': threads, 's_per_F': t_f, 's_per_X': t_x, 's_per_Theta': t_l,
+                      'parity': parity}))
 
 
 def cpu_model_name():
@@ -117,7 +138,7 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(config, iters, state_file):
+def cpu_baseline(config, iters, state_file, gpu_file=''):
     """Reference CPU path on the same workload, in child processes (a crash there cannot take the GPU measurement
     down): oracle/_ref (the real reference, OpenBLAS from the NumPy wheel) when present, else the C restatement;
     once on min(physical cores, 64) threads and once on 8.  The reference calls LAPACK posv
@@ -132,11 +153,13 @@ def cpu_baseline(config, iters, state_file):
             try:
                 res = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', kind,
                                       '--config', config, '--cpu-iters', str(iters), '--cpu-threads', str(threads),
-                                      '--cpu-state', state_file or ''], capture_output=True, text=True, timeout=1200)
+                                      '--cpu-state', state_file or '', '--cpu-gpu-result', gpu_file or ''],
+                                     capture_output=True, text=True, timeout=1200)
                 line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
                 r = json.loads(line)
                 runs.append({'threads': threads, 'iter_per_s': r['iters'] / r['seconds'], 'seconds': r['seconds'], 'iters': r['iters'],
-                             's_per_F_solve': r['s_per_F'], 's_per_X_solve': r['s_per_X'], 's_per_Theta_solve': r['s_per_Theta']})
+                             's_per_F_solve': r['s_per_F'], 's_per_X_solve': r['s_per_X'], 's_per_Theta_solve': r['s_per_Theta'],
+                             'parity_vs_gpu': r.get('parity')})
             except Exception as exc:   # noqa: BLE001 - keep whatever else succeeded
                 sys.stderr.write('cpu_baseline kind={} threads={} failed: {}\n'.format(kind, threads, exc))
         if runs:
@@ -159,10 +182,12 @@ def main():
     ap.add_argument('--cpu-iters', type=int, default=10)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-state', default='', help=argparse.SUPPRESS)
+    ap.add_argument('--cpu-gpu-result', default='', help=argparse.SUPPRESS)
     ap.add_argument('--cpu-baseline-worker', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args.config, args.cpu_iters, args.cpu_baseline_worker, args.cpu_threads, args.cpu_state)
+        return cpu_baseline_worker(args.config, args.cpu_iters, args.cpu_baseline_worker, args.cpu_threads, args.cpu_state,
+                                   args.cpu_gpu_result)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -280,11 +305,23 @@ def main():
             'setup_s': {'generate': t_gen, 'upload_and_alloc': t_up},
         }
         if not args.no_cpu_baseline and world == 1:
-            base = cpu_baseline(args.config, args.cpu_iters, state_file)
+            gpu_file = None
+            if state_file and missing:
+                # parity evidence at this size (untimed): the GPU repeats, from the state the timed window started from,
+                # kParityIters iterations that the CPU baseline's child also runs; the child compares objective and factors
+                z = np.load(state_file)
+                from trmf import Model
+                m2 = Model.from_arrays(z['W'], z['H'], z['lag_val'], prob['lag_set'])
+                with session.Session(prob['Y'], m2, missing=missing, log_norms=False, **hyper) as s2:
+                    s2.run(kParityIters).download()
+                gpu_file = state_file.replace('.npz', '_gpu.npz')
+                np.savez(gpu_file, W=m2.W, H=m2.H, lag_val=m2.lag_val)
+            base = cpu_baseline(args.config, args.cpu_iters, state_file, gpu_file)
             if base is not None:
                 out['cpu_baseline'] = base
-            if state_file and os.path.exists(state_file):
-                os.remove(state_file)
+            for f in (state_file, gpu_file):
+                if f and os.path.exists(f):
+                    os.remove(f)
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
