@@ -488,6 +488,15 @@ struct HvVecs {
     const real *Bv;       // GRAD: right-hand sides
 };
 
+// Workgroup b -> tile, such that the workgroups an XCD receives (b % 8 == x on gfx950's round-robin dispatch) own one
+// contiguous range of tiles.  A bijection on [0, n) for every n; changes only which workgroup does which tile.
+__device__ __forceinline__ int xcd_contiguous_tile(int b, int n) {
+    constexpr int kXcds = 8;
+    const int x = b % kXcds, i = b / kXcds;
+    const int base = n / kXcds, extra = n % kXcds;           // XCDs 0..extra-1 get base+1 workgroups
+    return x * base + min(x, extra) + i;
+}
+
 template <int MODE, int KQ>
 __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, int np_in,
                                                          int it, int last,
@@ -505,7 +514,11 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     const int tid = threadIdx.x;
     const int k = p.k, T = p.T, Hh = p.midx, nlag = p.nlag;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh, nV = rowsV * KP, nTh = nlag * k;
-    const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T);   // one tile per workgroup
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only, never correctness), so
+    // workgroups of one XCD take CONSECUTIVE tiles -- the halo rows a tile reads (its neighbours' r, d, H d of the
+    // previous launch) were then written through the same XCD's L2
+    const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int i0 = tile * TI, i1 = min(i0 + TI, T);          // one tile per workgroup
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
     real *rn = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
@@ -863,19 +876,19 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         block_allsum3(dot, rhd, hh, smem);
         if (threadIdx.x == 0) {
             double *Po = Pbase + (size_t)(P_CG0 + 3 * (it & 1)) * p.pstride;
-            Po[blockIdx.x] = dot; Po[(size_t)p.pstride + blockIdx.x] = rhd; Po[2 * (size_t)p.pstride + blockIdx.x] = hh;
+            Po[tile] = dot; Po[(size_t)p.pstride + tile] = rhd; Po[2 * (size_t)p.pstride + tile] = hh;
         }
         return;
     }
     block_allsum3(ar2, vv, dot, smem);
     if (GRAD) {
         lq = block_allsum(lq, smem);
-        if (threadIdx.x == 0) Pbase[P_LQ * (size_t)p.pstride + blockIdx.x] = lq;
+        if (threadIdx.x == 0) Pbase[P_LQ * (size_t)p.pstride + tile] = lq;
     }
     if (threadIdx.x == 0) {
-        Pbase[P_AR * (size_t)p.pstride + blockIdx.x] = ar2;
-        Pbase[P_VV * (size_t)p.pstride + blockIdx.x] = vv;
-        Pbase[P_DOT * (size_t)p.pstride + blockIdx.x] = dot;
+        Pbase[P_AR * (size_t)p.pstride + tile] = ar2;
+        Pbase[P_VV * (size_t)p.pstride + tile] = vv;
+        Pbase[P_DOT * (size_t)p.pstride + tile] = dot;
     }
 }
 
