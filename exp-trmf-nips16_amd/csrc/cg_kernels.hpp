@@ -16,6 +16,8 @@
 // Vectors are T x KP row-major (KP = padded rank); pad columns are zero and stay zero.
 #pragma once
 
+#include <vector>
+
 #include "common.hpp"
 
 namespace trmf {
@@ -128,10 +130,26 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const real *__restri
 // FUSE_DIR: the operand is the new direction d + (beta-1) d + r (rf_tron.h:494-502), written once for the own rows.
 // Partial sums of r^2 (AR part of fun) and v^2 (ridge part) go to slot blockIdx.y * gridDim.x + blockIdx.x.
 constexpr int kArCols = 8;
-constexpr int kArThreads = 1024;     // one workgroup per CU (its LDS tile is ~100 KB at the paper's lag set): 16 wavefronts hide the LDS latency
+constexpr int kArPitch = kArCols + 1; // LDS row pitch in elements: a thread owns kArU = 8 CONSECUTIVE rows of one column, so the 8 row groups of a
+                                      // wavefront sit 8 rows apart -- with 9 elements per row they fall into different bank groups (fp32 and fp64)
+constexpr int kArU = 8;               // rows per thread
+constexpr int kArRun = 4;             // consecutive lags handled as one sliding window: 11 LDS reads for 32 products instead of 32
+constexpr int kArThreads = 1024;      // one workgroup per CU (its LDS tile is ~118 KB at the paper's lag set)
 __host__ __device__ inline size_t ar_tile_lds_bytes(int TI, int midx, int nlag) {
-    return ((size_t)(TI + 2 * midx) * kArCols * sizeof(real) + (size_t)(TI + midx) * kArCols * sizeof(double) +
-            (size_t)nlag * kArCols * sizeof(real) + 63) / 16 * 16;
+    return ((size_t)(TI + 2 * midx + kArU) * kArPitch * sizeof(real) + 15) / 16 * 16 +
+           (size_t)(TI + midx + kArU) * kArPitch * sizeof(double) + ((size_t)nlag * kArCols * sizeof(real) + 15) / 16 * 16;
+}
+// The lag set as a list of steps in lag order: entry = (index of the first lag) * 2 + (1: that lag and the next three are
+// consecutive integers, handled as one window; 0: a single lag).  Same accumulation order as a plain loop over the lags.
+inline std::vector<uint32_t> ar_lag_steps(const uint32_t *lags, int nlag) {
+    std::vector<uint32_t> steps;
+    for (int l = 0; l < nlag;) {
+        bool run = l + kArRun <= nlag;
+        for (int j = 1; run && j < kArRun; j++) run = lags[l + j] == lags[l] + (uint32_t)j;
+        steps.push_back((uint32_t)l * 2 + (run ? 1 : 0));
+        l += run ? kArRun : 1;
+    }
+    return steps;
 }
 // fixed-order sum over a workgroup of kArThreads threads (16 wavefronts); identical in every thread
 __device__ __forceinline__ double block_allsum_wide(double v, double *smem /* >= 16 doubles */) {
@@ -143,6 +161,16 @@ __device__ __forceinline__ double block_allsum_wide(double v, double *smem /* >=
     for (int w = 0; w < kArThreads / 64; w++) r += smem[w];
     __syncthreads();
     return r;
+}
+__device__ __forceinline__ void block_allsum3_wide(double &a, double &b, double &c, double *smem /* >= 48 doubles */) {
+    a = wave_butterfly_sum(a); b = wave_butterfly_sum(b); c = wave_butterfly_sum(c);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { smem[w] = a; smem[16 + w] = b; smem[32 + w] = c; }
+    __syncthreads();
+    a = 0; b = 0; c = 0;
+#pragma unroll
+    for (int i = 0; i < kArThreads / 64; i++) { a += smem[i]; b += smem[16 + i]; c += smem[32 + i]; }
+    __syncthreads();
 }
 // MODE AR_PLAIN: base = AR/ridge part for the operand v (gradient at w, H s, first CG product).
 // MODE AR_CG_STEP: CG iteration it >= 1 of the unfused path, the counterpart of hv_tile_kernel<HV_CG_STEP>: the three
@@ -163,24 +191,54 @@ struct ArVecs {
 template <int MODE>
 __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *__restrict__ st, ArVecs a, int np, int it, int last,
                                                              const uint32_t *__restrict__ lag_set,
+                                                             const uint32_t *__restrict__ steps, int nsteps,
                                                              const real *__restrict__ theta,
                                                              real *__restrict__ base, double *__restrict__ Pbase, int TI) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ar_smem[];
-    __shared__ double smem[32];
+    __shared__ double smem[48];
     constexpr bool STEP = MODE == AR_CG_STEP;
     const int tid = threadIdx.x, T = p.T, KP = p.KP, Hh = p.midx, nlag = p.nlag;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
-    real *vs = reinterpret_cast<real *>(ar_smem);                                   // vs[row][col]
-    double *rs = reinterpret_cast<double *>(ar_smem + (((size_t)rowsV * kArCols * sizeof(real) + 15) / 16 * 16));
-    real *ths = reinterpret_cast<real *>(rs + (size_t)rowsR * kArCols);             // ths[l][col]
+    real *vs = reinterpret_cast<real *>(ar_smem);                                   // vs[row][col], pitch kArPitch, kArU spare rows
+    double *rs = reinterpret_cast<double *>(ar_smem + (((size_t)(rowsV + kArU) * kArPitch * sizeof(real) + 15) / 16 * 16));
+    real *ths = reinterpret_cast<real *>(rs + (size_t)(rowsR + kArU) * kArPitch);   // ths[l][col]
+    if (STEP && st->stop_it < it) return;               // an EARLIER launch ended the CG
+    const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
+    // The workgroup is a serial chain  partial sums -> alpha, beta -> operand rows -> residuals -> adjoint: the operand
+    // loads do not depend on the scalars, so the first batch is requested before anything else (and every later batch
+    // before the previous one is processed).
+    constexpr int kBatch = 4;
+    struct Batch { real v[kBatch], hd[kBatch], r[kBatch], s[kBatch]; };
+    const int nV = rowsV * kArCols;
+    auto request = [&](int e0) {
+        Batch b;
+#pragma unroll
+        for (int m = 0; m < kBatch; m++) {
+            const int e = e0 + m * kArThreads + tid, rr = e / kArCols, cc = e - rr * kArCols, i = i0 - Hh + rr;
+            b.v[m] = 0; b.hd[m] = 0; b.r[m] = 0; b.s[m] = 0;
+            if (e < nV && i >= 0 && i < T) {
+                const size_t ge = (size_t)i * KP + c0 + cc;
+                b.v[m] = a.v[ge];
+                if (STEP) {
+                    b.hd[m] = a.hd_in[ge]; b.r[m] = a.r_in[ge];
+                    if (i >= i0 && i < i1) b.s[m] = a.s[ge];
+                }
+            }
+        }
+        return b;
+    };
+    Batch cur = request(0);
+    for (int e = tid; e < nlag * kArCols; e += kArThreads) {
+        const int l = e / kArCols, cc = e - l * kArCols, t = collog(c0 + cc, p.NT);
+        ths[e] = t < p.k ? theta[(size_t)t * nlag + l] : real(0);
+    }
     real tmp = 0, alpha = 0, nalpha = 0;
     bool stopped = false;
     if (STEP) {
-        if (st->stop_it < it) return;                   // an EARLIER launch ended the CG
         const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
         double dHd = 0, rHd = 0, HH = 0;
         for (int i = tid; i < np; i += kArThreads) { dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i]; }
-        dHd = block_allsum_wide(dHd, smem); rHd = block_allsum_wide(rHd, smem); HH = block_allsum_wide(HH, smem);
+        block_allsum3_wide(dHd, rHd, HH, smem);
         const double rho_prev_d = st->rho_hist[it - 1];
         const real rho_prev = (real)rho_prev_d;
         alpha = rho_prev / (real)dHd;                                            // rf_tron.h:460
@@ -196,67 +254,80 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
             else st->cg_iter = it + 1;
         }
     }
-    const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
-    for (int e = tid; e < nlag * kArCols; e += kArThreads) {
-        const int l = e / kArCols, cc = e - l * kArCols, t = collog(c0 + cc, p.NT);
-        ths[e] = t < p.k ? theta[(size_t)t * nlag + l] : real(0);
-    }
     // (1) operand rows -> LDS (zeros outside [0, T)); CG step: s, r, d of the own rows go out
     double vv = 0, ar2 = 0;
-    for (int e = tid; e < rowsV * kArCols; e += kArThreads) {
-        const int rr = e / kArCols, cc = e - rr * kArCols, i = i0 - Hh + rr;
-        real x = 0;
-        if (i >= 0 && i < T) {
-            const size_t ge = (size_t)i * KP + c0 + cc;
-            x = a.v[ge];
-            const bool own = i >= i0 && i < i1;
-            if (STEP) {
-                const real rnew = fma(nalpha, a.hd_in[ge], a.r_in[ge]);            // r -= alpha Hd     (rf_tron.h:489-490)
-                if (own) a.s[ge] = fma(alpha, x, a.s[ge]);                         // s += alpha d      (rf_tron.h:461)
-                x = fma(tmp, x, x); x = x + rnew;                                  // d = beta d + r    (rf_tron.h:497-499)
-                if (own) { a.r_out[ge] = rnew; a.d_out[ge] = x; }
+    for (int e0 = 0; e0 < nV; e0 += kBatch * kArThreads) {
+        Batch nxt{};
+        if (e0 + kBatch * kArThreads < nV) nxt = request(e0 + kBatch * kArThreads);
+#pragma unroll
+        for (int m = 0; m < kBatch; m++) {
+            const int e = e0 + m * kArThreads + tid, rr = e / kArCols, cc = e - rr * kArCols, i = i0 - Hh + rr;
+            if (e >= nV) break;
+            real x = 0;
+            if (i >= 0 && i < T) {
+                const size_t ge = (size_t)i * KP + c0 + cc;
+                x = cur.v[m];
+                const bool own = i >= i0 && i < i1;
+                if (STEP) {
+                    const real rnew = fma(nalpha, cur.hd[m], cur.r[m]);            // r -= alpha Hd     (rf_tron.h:489-490)
+                    if (own) a.s[ge] = fma(alpha, x, cur.s[m]);                    // s += alpha d      (rf_tron.h:461)
+                    x = fma(tmp, x, x); x = x + rnew;                              // d = beta d + r    (rf_tron.h:497-499)
+                    if (own) { a.r_out[ge] = rnew; a.d_out[ge] = x; }
+                }
+                if (own) vv += (double)x * (double)x;
             }
-            if (own) vv += (double)x * (double)x;
+            vs[rr * kArPitch + cc] = x;
         }
-        vs[e] = x;
+        cur = nxt;
     }
     if (STEP && stopped) return;                        // s and r are final; no further product
     __syncthreads();
     const bool ar_on = nlag > 0 && p.lambdaAR > 0;
-    // (2) residuals of rows [i0, i0+TI+midx) (trmf.cpp:110-113 / 136-139): r = x_i - sum_l Theta_l x_{i-L_l}.
-    //     A thread keeps ONE column (kArThreads is a multiple of kArCols) and kArU rows at a time, so each Theta
-    //     element is read once per lag for kArU residuals; the lag offsets are wave-uniform (scalar cache, not LDS).
-    constexpr int kArU = 4, kRowStep = kArThreads / kArCols;
-    const int cc = tid % kArCols, r0 = tid / kArCols;
+    // (2) residuals of rows [i0, i0+TI+midx) (trmf.cpp:110-113 / 136-139): r = x_i - sum_l Theta_l x_{i-L_l}, lags in
+    //     order.  A thread keeps ONE column and kArU consecutive rows; over a run of kArRun consecutive lags the
+    //     operands of its rows overlap, so one window of kArU + kArRun - 1 LDS reads feeds kArU * kArRun products.
+    //     The step list and the lag offsets are wave-uniform (scalar loads).
+    constexpr int kGroups = kArThreads / kArCols, kWin = kArU + kArRun - 1;
+    const int cc = tid % kArCols, g = tid / kArCols;
     if (ar_on) {
-        for (int rb = r0; rb < rowsR; rb += kArU * kRowStep) {
+        for (int rb = g * kArU; rb < rowsR; rb += kGroups * kArU) {
             double res[kArU];
-            const real *col[kArU];
-            bool on[kArU];
+            const real *own = vs + (size_t)(rb + Hh) * kArPitch + cc;
 #pragma unroll
-            for (int u = 0; u < kArU; u++) {
-                const int rr = rb + u * kRowStep, i = i0 + rr;
-                on[u] = rr < rowsR && i >= Hh && i < T;
-                col[u] = vs + (size_t)((on[u] ? rr : 0) + Hh) * kArCols + cc;
-                res[u] = (double)col[u][0];
-            }
-#pragma unroll 2
-            for (int l = 0; l < nlag; l++) {
-                const real th = ths[l * kArCols + cc];
-                const ptrdiff_t back = (ptrdiff_t)lag_set[l] * kArCols;
+            for (int u = 0; u < kArU; u++) res[u] = (double)own[u * kArPitch];
+            for (int sidx = 0; sidx < nsteps; sidx++) {
+                const uint32_t step = steps[sidx];
+                const int l = (int)(step >> 1);
+                const real *win = own - (ptrdiff_t)lag_set[l] * kArPitch;
+                if (step & 1) {
+                    real x[kWin], th[kArRun];
 #pragma unroll
-                for (int u = 0; u < kArU; u++) {
-                    const real prod = th * col[u][-back];
-                    res[u] -= (double)prod;
+                    for (int m = 0; m < kWin; m++) x[m] = win[(m - (kArRun - 1)) * kArPitch];      // row rb + m - 3 - L
+#pragma unroll
+                    for (int j = 0; j < kArRun; j++) th[j] = ths[(l + j) * kArCols + cc];
+#pragma unroll
+                    for (int j = 0; j < kArRun; j++)
+#pragma unroll
+                        for (int u = 0; u < kArU; u++) {
+                            const real prod = th[j] * x[u - j + kArRun - 1];
+                            res[u] -= (double)prod;
+                        }
+                } else {
+                    const real th = ths[l * kArCols + cc];
+#pragma unroll
+                    for (int u = 0; u < kArU; u++) {
+                        const real prod = th * win[u * kArPitch];
+                        res[u] -= (double)prod;
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < kArU; u++) {
-                const int rr = rb + u * kRowStep;
+                const int rr = rb + u, i = i0 + rr;
                 if (rr < rowsR) {
-                    const double rv = on[u] ? res[u] : 0.0;                   // rows outside [midx, T): exact zeros
+                    const double rv = (i >= Hh && i < T) ? res[u] : 0.0;      // rows outside [midx, T): exact zeros
                     if (rr < TI) ar2 += rv * rv;
-                    rs[(size_t)rr * kArCols + cc] = rv;
+                    rs[(size_t)rr * kArPitch + cc] = rv;
                 }
             }
         }
@@ -265,34 +336,42 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
     // (3) base = lambdaI*v + lambdaAR*AR'(r) for the own rows: same rounding sequence as the reference's
     //     time-ordered scatter loop (own-row term first, then the lags in order).  Residual rows outside [midx, T)
     //     were stored as exact zeros, so the lagged terms need no range test.
-    for (int rb = r0; rb < i1 - i0; rb += kArU * kRowStep) {
+    for (int rb = g * kArU; rb < i1 - i0; rb += kGroups * kArU) {
         real o[kArU];
-        const double *rcol[kArU];
-        bool on[kArU];
+        const double *rown = rs + (size_t)rb * kArPitch + cc;
 #pragma unroll
         for (int u = 0; u < kArU; u++) {
-            const int rr = rb + u * kRowStep, i = i0 + rr;
-            on[u] = rr < i1 - i0;
-            const int rq = on[u] ? rr : 0;
-            const real x = vs[(size_t)(rq + Hh) * kArCols + cc];
+            const real x = vs[(size_t)(rb + u + Hh) * kArPitch + cc];
             if (p.lambdaI == 0) o[u] = 0;
             else if (p.lambdaI == 1) o[u] = x;
             else o[u] = (real)(p.lambdaI * (double)x);
-            rcol[u] = rs + (size_t)rq * kArCols + cc;
-            if (ar_on && i >= Hh) o[u] = (real)((double)o[u] + p.lambdaAR * rcol[u][0]);
+            if (ar_on && i0 + rb + u >= Hh) o[u] = (real)((double)o[u] + p.lambdaAR * rown[u * kArPitch]);
         }
         if (ar_on) {
-#pragma unroll 2
-            for (int l = 0; l < nlag; l++) {
-                const double lth = p.lambdaAR * (double)ths[l * kArCols + cc];
-                const size_t fwd = (size_t)lag_set[l] * kArCols;
+            for (int sidx = 0; sidx < nsteps; sidx++) {
+                const uint32_t step = steps[sidx];
+                const int l = (int)(step >> 1);
+                const double *win = rown + (size_t)lag_set[l] * kArPitch;
+                if (step & 1) {
+                    double y[kWin], lth[kArRun];
 #pragma unroll
-                for (int u = 0; u < kArU; u++) o[u] = (real)((double)o[u] - rcol[u][fwd] * lth);
+                    for (int m = 0; m < kWin; m++) y[m] = win[m * kArPitch];                       // row rb + m + L
+#pragma unroll
+                    for (int j = 0; j < kArRun; j++) lth[j] = p.lambdaAR * (double)ths[(l + j) * kArCols + cc];
+#pragma unroll
+                    for (int j = 0; j < kArRun; j++)
+#pragma unroll
+                        for (int u = 0; u < kArU; u++) o[u] = (real)((double)o[u] - y[u + j] * lth[j]);
+                } else {
+                    const double lth = p.lambdaAR * (double)ths[l * kArCols + cc];
+#pragma unroll
+                    for (int u = 0; u < kArU; u++) o[u] = (real)((double)o[u] - win[u * kArPitch] * lth);
+                }
             }
         }
 #pragma unroll
         for (int u = 0; u < kArU; u++)
-            if (on[u]) base[(size_t)(i0 + rb + u * kRowStep) * KP + c0 + cc] = o[u];
+            if (rb + u < i1 - i0) base[(size_t)(i0 + rb + u) * KP + c0 + cc] = o[u];
     }
     ar2 = block_allsum_wide(ar2, smem);
     vv = block_allsum_wide(vv, smem);

@@ -245,4 +245,123 @@ __global__ __launch_bounds__(256) void solve_rows_kernel(const real *__restrict_
     }
 }
 
+// ---- unfused CG with ONE Gram for every timestamp: out = base + V G (- B), on the matrix pipe -------------------
+// apply_kernel (cg_kernels.hpp) spends two LDS reads per multiply-add when the Gram is shared; here the product of a
+// 16-timestamp tile of the operand with the k x k Gram is KP/4 x NT fp64 MFMAs (fp32 sessions: operands widened, so
+// the accumulation stays in double as in apply_kernel).  The Gram is staged once per workgroup in LDS in VECTOR
+// POSITION order on both axes (zero in the pad positions), so tiles of the column-interleaved vectors are used as
+// they lie in memory.  A wavefront owns a tile: coalesced rows -> its LDS slab -> A fragments; base / residual /
+// right-hand side of the tile are requested before the MFMA loop and consumed in the accumulator layout.
+// Same outputs and partial-sum slots as apply_kernel (summation order differs).
+constexpr int kApplyTile = 16;
+__device__ __forceinline__ void wave_slab_sync() {      // LDS operations of one wavefront retire in order: a fence, no workgroup barrier
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__host__ __device__ constexpr int apply_gram_pitch(int KP) { return (KP % 32 == 16) ? KP : KP + 16; }   // doubles; B-fragment reads conflict-free
+__host__ __device__ constexpr int apply_tile_pitch(int KP) { return KP + 4; }                            // reals; A-fragment reads conflict-free
+__host__ __device__ constexpr size_t apply_shared_lds_bytes(int KP) {
+    return (size_t)KP * apply_gram_pitch(KP) * sizeof(double) + (size_t)4 * kApplyTile * apply_tile_pitch(KP) * sizeof(real);
+}
+template <int NT>
+__global__ __launch_bounds__(256) void apply_shared_mfma_kernel(XParams p, const XState *__restrict__ st, int cg_it,
+                                                                const real *__restrict__ v, const real *__restrict__ rvec,
+                                                                const real *__restrict__ base, const real *__restrict__ G,
+                                                                const real *__restrict__ Bv, int minus_b,
+                                                                real *__restrict__ out, int dot_mode,
+                                                                double *__restrict__ Pdot, int row0, int nrows, int slot0) {
+    constexpr int KP = kTile * NT, GP = apply_gram_pitch(KP), TP = apply_tile_pitch(KP), EPL = kApplyTile * KP / 64;
+    typedef Mfma16<double> M;
+    extern __shared__ __attribute__((aligned(16))) unsigned char apply_lds[];
+    __shared__ double smem[256];
+    const bool cg = cg_it >= 0;
+    if (cg && st->stop_it <= cg_it) return;               // see apply_kernel
+    double *Gs = reinterpret_cast<double *>(apply_lds);                                   // Gs[position kk][position cc]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k = p.k, c = lane & 15, g = lane >> 4;
+    real *tile = reinterpret_cast<real *>(Gs + (size_t)KP * GP) + (size_t)wave * kApplyTile * TP;
+    const int ntiles = (nrows + kApplyTile - 1) / kApplyTile, stride = gridDim.x * 4;
+    real raw[EPL];
+    auto load_raw = [&](int tidx) {                       // the tile's rows, coalesced
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int idx = e * 64 + lane, rr = idx / KP, i = tidx * kApplyTile + rr;
+            raw[e] = i < nrows ? v[(size_t)(row0 + i) * KP + (idx - rr * KP)] : real(0);
+        }
+    };
+    int tidx = blockIdx.x * 4 + wave;
+    if (tidx < ntiles) load_raw(tidx);
+    for (int e = threadIdx.x; e < KP * KP; e += 256) {
+        const int kk = e / KP, cc = e - kk * KP, s = collog(kk, NT), t = collog(cc, NT);
+        Gs[kk * GP + cc] = (s < k && t < k) ? (double)G[(size_t)s * k + t] : 0.0;
+    }
+    __syncthreads();
+    double dot = 0, lq = 0, rhd = 0, hh = 0;
+    for (; tidx < ntiles; tidx += stride) {
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int idx = e * 64 + lane, rr = idx / KP;
+            tile[rr * TP + (idx - rr * KP)] = raw[e];
+        }
+        wave_slab_sync();
+        if (tidx + stride < ntiles) load_raw(tidx + stride);
+        // operands of the epilogue, in the accumulator layout (row g + 4r, position 16 nt + c)
+        real ob[NT][4], rv[NT][4];
+        double bb[NT][4];
+        bool on[NT][4];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = tidx * kApplyTile + M::row(lane, r), pc = kTile * nt + c, t = collog(pc, NT);
+                const size_t row = (size_t)(row0 + i) * KP;
+                on[nt][r] = i < nrows && t < k;
+                ob[nt][r] = on[nt][r] ? base[row + pc] : real(0);               // lambdaI*v + lambdaAR*AR'(v), ar_tile_kernel
+                rv[nt][r] = (on[nt][r] && cg) ? rvec[row + pc] : real(0);
+                bb[nt][r] = (on[nt][r] && minus_b) ? (double)Bv[row + t] : 0.0;
+            }
+        typename M::acc_t acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++) acc[nt] = typename M::acc_t{0, 0, 0, 0};
+#pragma unroll 4
+        for (int ks = 0; ks < KP / 4; ks++) {
+            const double a = (double)tile[c * TP + 4 * ks + g];
+            const double *brow = Gs + (size_t)(4 * ks + g) * GP + c;
+#pragma unroll
+            for (int nt = 0; nt < NT; nt++) acc[nt] = M::mma(a, brow[kTile * nt], acc[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; nt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                if (!on[nt][r]) continue;
+                const int lrow = M::row(lane, r), pc = kTile * nt + c;
+                const real x = tile[lrow * TP + pc];
+                double a = acc[nt][r];
+                if (minus_b) {
+                    lq += (double)x * (a - 2.0 * bb[nt][r]);                     // w.(Gw) - 2 b.w
+                    a -= bb[nt][r];
+                }
+                const real o = (real)((double)ob[nt][r] + a);
+                out[(size_t)(row0 + tidx * kApplyTile + lrow) * KP + pc] = o;
+                dot += (double)(dot_mode ? x : o) * (double)o;
+                if (cg) {
+                    rhd += (double)rv[nt][r] * (double)o;                        // <r,Hd>
+                    hh += (double)o * (double)o;                                 // <Hd,Hd>
+                }
+            }
+        wave_slab_sync();                                 // the slab is rewritten by the next tile
+    }
+    if (cg) {
+        block_allsum3(dot, rhd, hh, smem);
+        if (threadIdx.x == 0) {
+            double *Po = Pdot + (size_t)(P_CG0 - P_DOT + 3 * (cg_it & 1)) * p.pstride + slot0 + blockIdx.x;
+            Po[0] = dot; Po[(size_t)p.pstride] = rhd; Po[2 * (size_t)p.pstride] = hh;
+        }
+        return;
+    }
+    dot = block_allsum(dot, smem);
+    lq = block_allsum(lq, smem);
+    if (threadIdx.x == 0) { Pdot[slot0 + blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + slot0 + blockIdx.x] = lq; }
+}
+
 }  // namespace trmf

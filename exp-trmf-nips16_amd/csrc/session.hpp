@@ -84,7 +84,8 @@ struct TrmfSessionImpl {
     std::vector<uint64_t> fbounds, xbounds;   // row partitions of items / timestamps
     // device
     hipStream_t stream = nullptr;
-    DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set;
+    DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set, lag_steps;   // lag_steps: ar_lag_steps() of the lag set
+    int nsteps = 0;
     DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, r1, d0, d1, Hd, Hd1, w_new;
     DevBuf<double> lossrow, partials, theta_part;
     // full-observation path (missing == 0)
@@ -205,6 +206,11 @@ struct TrmfSessionImpl {
         }
         set_trYTY();
         if (lag_set.upload(lags, nlag)) return kFail;
+        {
+            const std::vector<uint32_t> steps = ar_lag_steps(lags, nlag);
+            nsteps = (int)steps.size();
+            if (lag_steps.upload(steps.data(), steps.size())) return kFail;
+        }
         if (upload_padded(W, (const real *)Wm->val, T)) return kFail;
         if (upload_padded(H, (const real *)Hm->val, n)) return kFail;
         if (theta.upload((const real *)LVm->val, (size_t)nlag * k)) return kFail;
@@ -275,6 +281,19 @@ struct TrmfSessionImpl {
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
         nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
+        if (full) {      // apply_shared_mfma_kernel: a 16-row tile per wavefront and pass, <= 2 workgroups per CU resident, equal passes
+            const int blocks = ((T + kApplyTile - 1) / kApplyTile + 3) / 4, passes = (blocks + 511) / 512;
+            nba = std::max(1, (blocks + passes - 1) / passes);
+            const size_t need = apply_shared_lds_bytes(KP);
+            int rc = 0;
+            switch (NT) {
+                case 1: rc = allow_dyn_lds(apply_shared_mfma_kernel<1>, need, "shared-Gram product"); break;
+                case 2: rc = allow_dyn_lds(apply_shared_mfma_kernel<2>, need, "shared-Gram product"); break;
+                case 3: rc = allow_dyn_lds(apply_shared_mfma_kernel<3>, need, "shared-Gram product"); break;
+                default: rc = allow_dyn_lds(apply_shared_mfma_kernel<4>, need, "shared-Gram product"); break;
+            }
+            if (rc) return kFail;
+        }
         tile_TI = 0; nbt = 1;
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
             int TI = hv_tile_rows(k);
@@ -286,9 +305,26 @@ struct TrmfSessionImpl {
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
         }
-        {   // unfused path: AR tile = the largest power of two of timestamps whose halo fits a 120 KB LDS budget
-            ar_TI = 512;
-            while (ar_TI > 32 && ar_tile_lds_bytes(ar_TI, midx, nlag) > 120 * 1024) ar_TI /= 2;
+        {   // unfused path: timestamps per AR tile.  One workgroup per CU (LDS); a tile costs ~(TI + 2 midx) staged rows,
+            // (TI + midx) residual rows and TI output rows, and the grid runs in ceil(tiles * column groups / CUs) rounds:
+            // take the tile count with the cheapest schedule among those whose halo fits the 150 KB LDS budget.
+            hipDeviceProp_t prop;
+            int dev = 0;
+            TRMF_HIP_CHECK(hipGetDevice(&dev));
+            TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            const int cus = std::max(1, prop.multiProcessorCount), groups = KP / kArCols;
+            int ti_max = (T + kArU - 1) / kArU * kArU;
+            while (ti_max > kArU && ar_tile_lds_bytes(ti_max, midx, nlag) > 150 * 1024) ti_max = std::max(kArU, (ti_max / 2 + kArU - 1) / kArU * kArU);
+            while (ti_max + kArU <= T && ar_tile_lds_bytes(ti_max + kArU, midx, nlag) <= 150 * 1024) ti_max += kArU;
+            const int nt_min = (T + ti_max - 1) / ti_max;
+            double best = 0;
+            for (int nt = nt_min; nt <= 4 * nt_min + 1; nt++) {
+                const int ti = ((T + nt - 1) / nt + kArU - 1) / kArU * kArU;
+                const int tiles = (T + ti - 1) / ti;
+                const double cost = (double)((tiles * groups + cus - 1) / cus) * (3.0 * ti + 3.0 * midx + 64);
+                if (best == 0 || cost < best) { best = cost; ar_TI = ti; }
+            }
+            if (const char *e = getenv("TRMF_AR_TI")) ar_TI = std::max(kArU, atoi(e) / kArU * kArU);   // experiments
             const size_t need = ar_tile_lds_bytes(ar_TI, midx, nlag);
             if (allow_dyn_lds(ar_tile_kernel<AR_PLAIN>, need, "AR operator (max lag too large)") ||
                 allow_dyn_lds(ar_tile_kernel<AR_CG_STEP>, need, "AR operator (max lag too large)"))
@@ -762,14 +798,27 @@ struct TrmfSessionImpl {
         const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
         if (cg_it >= 1)
             hipLaunchKernelGGL((ar_tile_kernel<AR_CG_STEP>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, av, ndot, cg_it, last,
-                               lag_set.p, theta.p, arbase.p, Pb, ar_TI);
+                               lag_set.p, lag_steps.p, nsteps, theta.p, arbase.p, Pb, ar_TI);
         else
             hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, av, ndot, 0, 0,
-                               lag_set.p, theta.p, arbase.p, Pb, ar_TI);
+                               lag_set.p, lag_steps.p, nsteps, theta.p, arbase.p, Pb, ar_TI);
         if (last) return 0;                                              // the closing launch has no product
         const real *operand = cg_it >= 1 ? av.d_out : av.v;
         const real *resid = cg_it >= 1 ? av.r_out : av.r_in;
         const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : 0;        // shared Gram staged per workgroup
+        if (full && !getenv("TRMF_NO_APPLY_SHARED")) {       // one Gram for every timestamp: the product runs on the matrix pipe (never sharded)
+#define TRMF_LAUNCH_APPLY_SHARED(NTV)                                                                                           \
+    hipLaunchKernelGGL((apply_shared_mfma_kernel<NTV>), dim3(nba), dim3(256), apply_shared_lds_bytes(KP), stream, xp, st, cg_it,  \
+                       operand, resid, arbase.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), 0, T, 0)
+            switch (NT) {
+                case 1: TRMF_LAUNCH_APPLY_SHARED(1); break;
+                case 2: TRMF_LAUNCH_APPLY_SHARED(2); break;
+                case 3: TRMF_LAUNCH_APPLY_SHARED(3); break;
+                default: TRMF_LAUNCH_APPLY_SHARED(4); break;
+            }
+#undef TRMF_LAUNCH_APPLY_SHARED
+            return 0;
+        }
         if (!cg_shard) {
             hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
                                Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, 0, T, 0);
@@ -989,8 +1038,8 @@ struct TrmfSessionImpl {
             ArVecs av{};
             av.v = W.p;
             hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), dim3((T + ar_TI - 1) / ar_TI, KP / kArCols), dim3(kArThreads),
-                               ar_tile_lds_bytes(ar_TI, midx, nlag), stream, xp, st, av, 0, 0, 0, lag_set.p, theta.p, arbase.p,
-                               partials.p, ar_TI);
+                               ar_tile_lds_bytes(ar_TI, midx, nlag), stream, xp, st, av, 0, 0, 0, lag_set.p, lag_steps.p, nsteps,
+                               theta.p, arbase.p, partials.p, ar_TI);
         }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_AR), nbar, &st->gs);
         const double ar = host_double(&st->gs);
