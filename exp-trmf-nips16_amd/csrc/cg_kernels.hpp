@@ -135,9 +135,13 @@ constexpr int kArPitch = kArCols + 1; // LDS row pitch in elements: a thread own
 constexpr int kArU = 8;               // rows per thread
 constexpr int kArRun = 4;             // consecutive lags handled as one sliding window: 11 LDS reads for 32 products instead of 32
 constexpr int kArThreads = 1024;      // one workgroup per CU (its LDS tile is ~118 KB at the paper's lag set)
+// One pass (every residual of the tile in registers at once) lets the residual rows reuse the operand rows' LDS.
+__host__ __device__ inline bool ar_tile_one_pass(int TI, int midx) { return TI + midx <= kArThreads / kArCols * kArU; }
 __host__ __device__ inline size_t ar_tile_lds_bytes(int TI, int midx, int nlag) {
-    return ((size_t)(TI + 2 * midx + kArU) * kArPitch * sizeof(real) + 15) / 16 * 16 +
-           (size_t)(TI + midx + kArU) * kArPitch * sizeof(double) + ((size_t)nlag * kArCols * sizeof(real) + 15) / 16 * 16;
+    const size_t vbytes = ((size_t)(TI + 2 * midx + kArU) * kArPitch * sizeof(real) + 15) / 16 * 16;
+    const size_t rbytes = (size_t)(TI + midx + kArU) * kArPitch * sizeof(double);
+    const size_t rows = ar_tile_one_pass(TI, midx) ? (vbytes > rbytes ? vbytes : rbytes) : vbytes + rbytes;
+    return rows + ((size_t)nlag * kArCols * sizeof(real) + 15) / 16 * 16;
 }
 // The lag set as a list of steps in lag order: entry = (index of the first lag) * 2 + (1: that lag and the next three are
 // consecutive integers, handled as one window; 0: a single lag).  Same accumulation order as a plain loop over the lags.
@@ -199,9 +203,14 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
     constexpr bool STEP = MODE == AR_CG_STEP;
     const int tid = threadIdx.x, T = p.T, KP = p.KP, Hh = p.midx, nlag = p.nlag;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh;
-    real *vs = reinterpret_cast<real *>(ar_smem);                                   // vs[row][col], pitch kArPitch, kArU spare rows
-    double *rs = reinterpret_cast<double *>(ar_smem + (((size_t)(rowsV + kArU) * kArPitch * sizeof(real) + 15) / 16 * 16));
-    real *ths = reinterpret_cast<real *>(rs + (size_t)(rowsR + kArU) * kArPitch);   // ths[l][col]
+    // vs[row][col] (operand rows) and rs[row][col] (residual rows), pitch kArPitch, kArU spare rows each; in the
+    // one-pass form rs REUSES the memory of vs (every thread holds its residuals in registers across a barrier)
+    const bool one_pass = ar_tile_one_pass(TI, Hh);
+    const size_t vbytes = ((size_t)(rowsV + kArU) * kArPitch * sizeof(real) + 15) / 16 * 16;
+    const size_t rbytes = (size_t)(rowsR + kArU) * kArPitch * sizeof(double);
+    real *vs = reinterpret_cast<real *>(ar_smem);
+    double *rs = reinterpret_cast<double *>(ar_smem + (one_pass ? 0 : vbytes));
+    real *ths = reinterpret_cast<real *>(ar_smem + (one_pass ? (vbytes > rbytes ? vbytes : rbytes) : vbytes + rbytes));   // ths[l][col]
     if (STEP && st->stop_it < it) return;               // an EARLIER launch ended the CG
     const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
     // The workgroup is a serial chain  partial sums -> alpha, beta -> operand rows -> residuals -> adjoint: the operand
@@ -289,47 +298,67 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
     //     The step list and the lag offsets are wave-uniform (scalar loads).
     constexpr int kGroups = kArThreads / kArCols, kWin = kArU + kArRun - 1;
     const int cc = tid % kArCols, g = tid / kArCols;
-    if (ar_on) {
-        for (int rb = g * kArU; rb < rowsR; rb += kGroups * kArU) {
-            double res[kArU];
-            const real *own = vs + (size_t)(rb + Hh) * kArPitch + cc;
+    auto residuals = [&](int rb, double (&res)[kArU]) {
+        const real *own = vs + (size_t)(rb + Hh) * kArPitch + cc;
 #pragma unroll
-            for (int u = 0; u < kArU; u++) res[u] = (double)own[u * kArPitch];
-            for (int sidx = 0; sidx < nsteps; sidx++) {
-                const uint32_t step = steps[sidx];
-                const int l = (int)(step >> 1);
-                const real *win = own - (ptrdiff_t)lag_set[l] * kArPitch;
-                if (step & 1) {
-                    real x[kWin], th[kArRun];
+        for (int u = 0; u < kArU; u++) res[u] = (double)own[u * kArPitch];
+        for (int sidx = 0; sidx < nsteps; sidx++) {
+            const uint32_t step = steps[sidx];
+            const int l = (int)(step >> 1);
+            const real *win = own - (ptrdiff_t)lag_set[l] * kArPitch;
+            if (step & 1) {
+                real x[kWin], th[kArRun];
 #pragma unroll
-                    for (int m = 0; m < kWin; m++) x[m] = win[(m - (kArRun - 1)) * kArPitch];      // row rb + m - 3 - L
+                for (int m = 0; m < kWin; m++) x[m] = win[(m - (kArRun - 1)) * kArPitch];      // row rb + m - 3 - L
 #pragma unroll
-                    for (int j = 0; j < kArRun; j++) th[j] = ths[(l + j) * kArCols + cc];
+                for (int j = 0; j < kArRun; j++) th[j] = ths[(l + j) * kArCols + cc];
 #pragma unroll
-                    for (int j = 0; j < kArRun; j++)
-#pragma unroll
-                        for (int u = 0; u < kArU; u++) {
-                            const real prod = th[j] * x[u - j + kArRun - 1];
-                            res[u] -= (double)prod;
-                        }
-                } else {
-                    const real th = ths[l * kArCols + cc];
+                for (int j = 0; j < kArRun; j++)
 #pragma unroll
                     for (int u = 0; u < kArU; u++) {
-                        const real prod = th * win[u * kArPitch];
+                        const real prod = th[j] * x[u - j + kArRun - 1];
                         res[u] -= (double)prod;
                     }
-                }
-            }
+            } else {
+                const real th = ths[l * kArCols + cc];
 #pragma unroll
-            for (int u = 0; u < kArU; u++) {
-                const int rr = rb + u, i = i0 + rr;
-                if (rr < rowsR) {
-                    const double rv = (i >= Hh && i < T) ? res[u] : 0.0;      // rows outside [midx, T): exact zeros
-                    if (rr < TI) ar2 += rv * rv;
-                    rs[(size_t)rr * kArPitch + cc] = rv;
+                for (int u = 0; u < kArU; u++) {
+                    const real prod = th * win[u * kArPitch];
+                    res[u] -= (double)prod;
                 }
             }
+        }
+    };
+    auto keep_residuals = [&](int rb, const double (&res)[kArU]) {
+#pragma unroll
+        for (int u = 0; u < kArU; u++) {
+            const int rr = rb + u, i = i0 + rr;
+            if (rr < rowsR) {
+                const double rv = (i >= Hh && i < T) ? res[u] : 0.0;          // rows outside [midx, T): exact zeros
+                if (rr < TI) ar2 += rv * rv;
+                rs[(size_t)rr * kArPitch + cc] = rv;
+            }
+        }
+    };
+    real xown[kArU];                                    // one pass: the thread's own operand rows, for step (3)
+#pragma unroll
+    for (int u = 0; u < kArU; u++) xown[u] = 0;
+    if (one_pass) {
+        const int rb = g * kArU;
+        double res[kArU];
+        const bool act = ar_on && rb < rowsR;
+        if (rb < i1 - i0) {
+#pragma unroll
+            for (int u = 0; u < kArU; u++) xown[u] = vs[(size_t)(rb + u + Hh) * kArPitch + cc];
+        }
+        if (act) residuals(rb, res);
+        __syncthreads();                                // every read of the operand rows is done: their memory becomes rs
+        if (act) keep_residuals(rb, res);
+    } else if (ar_on) {
+        for (int rb = g * kArU; rb < rowsR; rb += kGroups * kArU) {
+            double res[kArU];
+            residuals(rb, res);
+            keep_residuals(rb, res);
         }
     }
     __syncthreads();
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
         const double *rown = rs + (size_t)rb * kArPitch + cc;
 #pragma unroll
         for (int u = 0; u < kArU; u++) {
-            const real x = vs[(size_t)(rb + u + Hh) * kArPitch + cc];
+            const real x = one_pass ? xown[u] : vs[(size_t)(rb + u + Hh) * kArPitch + cc];
             if (p.lambdaI == 0) o[u] = 0;
             else if (p.lambdaI == 1) o[u] = x;
             else o[u] = (real)(p.lambdaI * (double)x);

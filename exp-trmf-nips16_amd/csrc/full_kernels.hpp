@@ -218,6 +218,37 @@ __global__ __launch_bounds__(256) void chol_shared_kernel(const real *__restrict
     }
     for (int e = threadIdx.x; e < k * k; e += 256) Uout[e] = U[e];
 }
+// chol_wave_kernel: the same factorisation by ONE wavefront without LDS or barriers.  Lane c keeps column c of the
+// matrix in registers (KMAX values; rows and columns >= k padded with the identity, so no step needs a guard); step
+// j scales row j and subtracts u_js * u_jc from every later row s, u_js arriving as a scalar through v_readlane
+// with a compile-time lane -- the loops are fully unrolled.  Same operations per element as chol_shared_kernel
+// (sqrt, divide, one fused multiply-subtract), ~4x faster at k = 60 (70 -> 18 us): the workgroup version is a chain
+// of 3 k barriers and LDS round trips.  Writes U (upper part, zeros below).
+template <int NT>
+__global__ __launch_bounds__(64) void chol_wave_kernel(const real *__restrict__ GS, real *__restrict__ Uout, int k) {
+    constexpr int KMAX = kTile * NT;
+    const int c = threadIdx.x;
+    real a[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; s++) a[s] = (s < k && c < k) ? GS[(size_t)s * k + c] : (s == c ? real(1) : real(0));
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+        const real ajj = sqrt(lane_bcast(a[j], j));
+        const real u = (c == j) ? ajj : a[j] / ajj;
+        a[j] = u;
+#pragma unroll
+        for (int s = j + 1; s < KMAX; s++) {
+            a[s] = fma(-lane_bcast(u, s), u, a[s]);
+            if ((s & 15) == 15) __builtin_amdgcn_sched_barrier(0);       // bound the scalar operands in flight
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c < k) {
+#pragma unroll
+        for (int s = 0; s < KMAX; s++)
+            if (s < k) Uout[(size_t)s * k + c] = s <= c ? a[s] : real(0);
+    }
+}
 // dynamic LDS = k * k * sizeof(real); k <= 64: lane p holds unknown p
 __global__ __launch_bounds__(256) void solve_rows_kernel(const real *__restrict__ Ug, const real *__restrict__ Brows,
                                                          real *__restrict__ out, int rows, int k, int KP, int NT) {

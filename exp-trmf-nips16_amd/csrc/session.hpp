@@ -307,7 +307,8 @@ struct TrmfSessionImpl {
         }
         {   // unfused path: timestamps per AR tile.  One workgroup per CU (LDS); a tile costs ~(TI + 2 midx) staged rows,
             // (TI + midx) residual rows and TI output rows, and the grid runs in ceil(tiles * column groups / CUs) rounds:
-            // take the tile count with the cheapest schedule among those whose halo fits the 150 KB LDS budget.
+            // take the tile count with the cheapest schedule among those whose halo fits the 150 KB LDS budget (tiles of at
+            // most 1024 - midx timestamps keep all residuals in registers and need half the LDS: ar_tile_one_pass).
             hipDeviceProp_t prop;
             int dev = 0;
             TRMF_HIP_CHECK(hipGetDevice(&dev));
@@ -321,7 +322,8 @@ struct TrmfSessionImpl {
             for (int nt = nt_min; nt <= 4 * nt_min + 1; nt++) {
                 const int ti = ((T + nt - 1) / nt + kArU - 1) / kArU * kArU;
                 const int tiles = (T + ti - 1) / ti;
-                const double cost = (double)((tiles * groups + cus - 1) / cus) * (3.0 * ti + 3.0 * midx + 64);
+                // a round is dominated by the tile's serial chain (measured: 15.2 us at TI=280, 16.0 us at TI=416), rows add little
+                const double cost = (double)((tiles * groups + cus - 1) / cus) * (3.0 * ti + 3.0 * midx + 2000);
                 if (best == 0 || cost < best) { best = cost; ar_TI = ti; }
             }
             if (const char *e = getenv("TRMF_AR_TI")) ar_TI = std::max(kArU, atoi(e) / kArU * kArU);   // experiments
@@ -732,7 +734,13 @@ struct TrmfSessionImpl {
         small_gram(W.p, T, (real)lambdaI, GSf.p);                                                       // W^T W + lambda I
         if (re > rb) {
             const size_t ulds = (size_t)k * k * sizeof(real);          // <= 32 KB
-            hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
+            if (getenv("TRMF_CHOL_WORKGROUP")) hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
+            else switch (NT) {
+                case 1: hipLaunchKernelGGL(chol_wave_kernel<1>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
+                case 2: hipLaunchKernelGGL(chol_wave_kernel<2>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
+                case 3: hipLaunchKernelGGL(chol_wave_kernel<3>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
+                default: hipLaunchKernelGGL(chol_wave_kernel<4>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
+            }
             const int nrows = (int)(re - rb), nblk = std::max(1, std::min(2048, (nrows + 3) / 4));
             hipLaunchKernelGGL(solve_rows_kernel, dim3(nblk), dim3(256), ulds, stream, Uf.p, Bf.p + (size_t)rb * KP,
                                H.p + (size_t)rb * KP, nrows, k, KP, NT);
