@@ -79,3 +79,34 @@ def test_random_period_gating_vs_restatement(seed):
     if periods[0] > 5: assert np.array_equal(model.W, m0.W)
     if periods[1] > 5: assert np.array_equal(model.H, m0.H)
     if periods[2] > 5: assert np.array_equal(model.lag_val, m0.lag_val)
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+@pytest.mark.parametrize('T,lags,k,ar_ti,missing', [
+    (1100, [1, 2, 3, 4, 7, 200], 8, None, True),                            # one tile, TI + max lag > 1024: two-buffer layout, two passes
+    (3000, [1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 30], 20, None, True),      # runs of four between single lags, one-pass tiles
+    (3000, [1, 2, 3, 4, 5, 6, 9, 10, 11, 12, 13, 30], 20, 64, False),       # the same with many small tiles, shared-Gram product
+    (2500, [2, 3, 4, 5, 400], 33, None, True),                              # long reach, k = 33 (KP = 48: six column groups)
+    (1500, list(range(1, 17)) + [97, 98, 99, 100], 60, 944, False),         # forced TI beyond one pass (944 + 100 > 1024), 155 KB of LDS in fp64
+])
+def test_unfused_ar_tile_layouts(dtype, T, lags, k, ar_ti, missing, monkeypatch):
+    """The unfused CG's AR tile kernel in each of its forms: lag sets split into runs of four consecutive lags and single
+    lags (ar_lag_steps), residual rows reusing the operand rows' LDS (one pass) or not, one tile or many -- three ALS
+    iterations against the restatement at the 8(d) gates."""
+    monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
+    if ar_ti is not None:
+        monkeypatch.setenv('TRMF_AR_TI', str(ar_ti))
+    n = 40
+    rng = np.random.RandomState(7)
+    d = trmf.Model.syn_gen(T, n, 6, [1, 2], seed=7, dtype=np.float64)
+    Yd = (d['Y'] + 0.05 * rng.randn(T, n)).astype(dtype)
+    Y = smat.csr_matrix(np.where(rng.rand(T, n) < 0.5, Yd, 0)) if missing else np.ascontiguousarray(Yd)
+    hyper = dict(lambdaI=0.5, lambdaAR=50.0, lambdaLag=0.5)
+    m0 = trmf.Model.initialize(Y, lags, k, seed=3, dtype=dtype)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=3, missing=missing, threads=4)
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    trmf.train(Y, model, max_iter=3, missing=missing, **hyper)
+    fac = TOL[np.dtype(dtype).name]['factor']
+    print('T=%d lags=%s k=%d TI=%s %s: relfro W %.1e H %.1e Th %.1e' % (T, lags, k, ar_ti, np.dtype(dtype).name, relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th)))
+    assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac
