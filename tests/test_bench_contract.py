@@ -30,3 +30,27 @@ def test_cpu_baseline_worker_protocol():
     r = json.loads(line)
     assert r['iters'] == 3 and r['threads'] == 2
     assert all(r[key] > 0 for key in ('seconds', 's_per_F', 's_per_X', 's_per_Theta'))
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_bench_through_the_launcher_line_with_one_rank():
+    """The driver's N > 1 command with N = 1: torch.distributed.run -> NCCL(=RCCL) process group -> the library's own RCCL
+    communicator (unique id broadcast, grouped in-place broadcasts on a 1-rank communicator) -> barriers and the
+    MAX-over-ranks all-reduce -> one JSON line from rank 0.  With one rank every branch of the multi-GPU path runs."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, TRMF_BENCH_FORCE_DIST='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+           '--config', 'c2', '--no-cpu-baseline']
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 1 and r['steps'] == 3 and r['value'] > 0 and r['metric'] == 'als_iterations_per_sec'
+    assert r['roofline']['achieved'] > 0
