@@ -294,7 +294,7 @@ def main():
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
                 args.config, cfg['n'], cfg['T'], cfg.get('density', 1.0), nnz, cfg['k'], len(prob['lag_set']), dtype.name,
                 int(missing), hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
-                'parallelism': 'item rows of the F-solve and timestamp rows of the X-side Gram build sharded x{} with RCCL all-gathers, each replicated instead when its all-gather costs more than it saves (decided once, from the first measured iteration); fused CG replicated (long-lag / large-T problems: cached-Gram product sharded, H d all-gathered per step)'.format(world)},
+                'parallelism': 'item rows of the F-solve and timestamp rows of the X-side Gram build sharded x{} with RCCL all-gathers, each replicated instead when its all-gather costs more than it saves (decided once, from the timings of the second iteration); fused CG replicated (long-lag / large-T problems: cached-Gram product sharded, H d all-gathered per step)'.format(world)},
             'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_grid_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,

@@ -231,6 +231,14 @@ struct TrmfSessionImpl {
         if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
         if (const char *e = getenv("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
         TRMF_HIP_CHECK(hipDeviceSynchronize());
+        if (comm->world > 1) {
+            // one small gather now: the communicator's connections are set up before the ALS loop (and before the timed
+            // gathers of the shard decisions).  The values are this rank's own zeros, the buffer is rewritten before use.
+            std::vector<uint64_t> off(comm->world + 1);
+            for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * 2 * sizeof(double);
+            if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        }
         return 0;
     }
 
@@ -555,7 +563,7 @@ struct TrmfSessionImpl {
     }
     // Sharding a phase over the ranks pays only when the all-gather of its result costs less than the rows a rank no
     // longer computes (true for the F-solve at config 3 on 4 and 8 GPUs, not on 2).  Measure-once rule, shared by the
-    // F-solve and the X-side Gram build: the first call runs sharded and is timed on every rank (kernel, gather); the
+    // F-solve and the X-side Gram build: the first two calls run sharded, the second is timed on every rank (kernel, gather); the
     // times are exchanged through the communicator and every rank takes the same decision.
     enum { kShardMeasure = 0, kShardOn = 1, kShardOff = 2 };
     int decide_shard(hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, const char *what) {
@@ -585,12 +593,14 @@ struct TrmfSessionImpl {
     int fs_mode = kShardMeasure, fs_calls = 0;
     hipEvent_t fs0 = nullptr, fs1 = nullptr, fs2 = nullptr;
     int fsolve(PhaseEvents &ev) {
-        if (fs_mode == kShardMeasure && fs_calls == 1) {
+        // the SECOND call is the measured one: the first carries one-time costs on both sides of the comparison (code
+        // object load of the kernel, connection set-up inside the first collective)
+        if (fs_mode == kShardMeasure && fs_calls == 2) {
             const int m = decide_shard(fs0, fs1, fs2, "F-solve");
             if (m < 0) return kFail;
             fs_mode = m;
         }
-        const bool replicate = fs_mode == kShardOff, measure = fs_mode == kShardMeasure;
+        const bool replicate = fs_mode == kShardOff, measure = fs_mode == kShardMeasure && fs_calls == 1;
         const uint32_t rb = replicate ? 0u : (uint32_t)fbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)n : (uint32_t)fbounds[comm->rank + 1];
         if (measure) TRMF_HIP_CHECK(hipEventRecord(fs0, stream));
@@ -623,9 +633,9 @@ struct TrmfSessionImpl {
                                Yr_val.p, H.p, Wv, lossrow.p, rb, re, (uint32_t)n);
     }
     int gram_x() {
-        if (!cg_shard && gramx_mode == kGramxMeasure && gramx_calls == 1 && gramx_decide()) return kFail;
+        if (!cg_shard && gramx_mode == kGramxMeasure && gramx_calls == 2 && gramx_decide()) return kFail;   // second call measured, see fsolve()
         const bool replicate = gramx_mode == kGramxReplicate && !cg_shard;
-        const bool measure = gramx_mode == kGramxMeasure && !cg_shard;
+        const bool measure = gramx_mode == kGramxMeasure && !cg_shard && gramx_calls == 1;
         const uint32_t rb = replicate ? 0u : (uint32_t)xbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)T : (uint32_t)xbounds[comm->rank + 1];
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx0, stream));
@@ -645,7 +655,7 @@ struct TrmfSessionImpl {
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx2, stream));
         return 0;
     }
-    // One-time decision after the first (measured, sharded) build.  Rank r publishes (kernel ms, gather ms);
+    // One-time decision after the second (measured, sharded) build.  Rank r publishes (kernel ms, gather ms);
     // after the exchange every rank evaluates the same rule on the same numbers.
     int gramx_decide() {
         const int m = decide_shard(gx0, gx1, gx2, "X-side Gram build");
