@@ -30,8 +30,9 @@ __device__ __forceinline__ void theta_decode_pair(int p, int nlag, int &a, int &
 // of 2).  Products are rounded to val_type, sums are double (trmf.cpp:447-453); the S slice sums of a block are added
 // in fixed order through LDS.
 constexpr int kThetaTile = 4;
+constexpr int kThetaRows = 4;     // consecutive timestamps per pass of the sliding-window path
 __host__ __device__ inline size_t theta_gram_lds_bytes(int midx) {
-    return ((size_t)(kThetaChunk + midx) * sizeof(real) + 15) / 16 * 16 + (size_t)256 * 16 * sizeof(double);
+    return ((size_t)(kThetaChunk + midx + kThetaRows) * sizeof(real) + 15) / 16 * 16 + (size_t)256 * 16 * sizeof(double);   // + window slack
 }
 __global__ __launch_bounds__(256) void theta_gram_kernel(const real *__restrict__ W, int T, int KP,
                                                          const uint32_t *__restrict__ lag_set,
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void theta_gram_kernel(const real *__restrict_
                                                          double *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     real *series = reinterpret_cast<real *>(smem_raw);
-    double *red = reinterpret_cast<double *>(smem_raw + (((size_t)(kThetaChunk + midx) * sizeof(real) + 15) / 16 * 16));
+    double *red = reinterpret_cast<double *>(smem_raw + (((size_t)(kThetaChunk + midx + kThetaRows) * sizeof(real) + 15) / 16 * 16));
     const int t = blockIdx.x, ch = blockIdx.y, nchunk = gridDim.y;
     const int i0 = midx + ch * kThetaChunk;
     const int i1 = min(T, i0 + kThetaChunk);
@@ -71,7 +72,37 @@ __global__ __launch_bounds__(256) void theta_gram_kernel(const real *__restrict_
         for (int u = 0; u < kThetaTile; u++)
 #pragma unroll
             for (int v = 0; v < kThetaTile; v++) acc[u][v] = 0;
-        if (live) {
+        // Blocks whose four lags are consecutive integers on both sides (all of the paper's lag set, every 1..|L| set):
+        // a thread then takes kThetaRows consecutive timestamps per pass -- the operands of neighbouring rows and lags
+        // overlap, so two windows of kThetaRows + 3 LDS reads feed 16 kThetaRows products (0.22 reads per product
+        // instead of 0.5; the kernel is LDS-bound).  Other blocks take the general loop below.
+        bool runs = live;
+#pragma unroll
+        for (int u = 1; u < kThetaTile; u++)
+            runs = runs && (rhs || la[u] == la[0] + u) && lb[u] == lb[0] + u;
+        if (runs) {
+            constexpr int R = kThetaRows, Wn = R + kThetaTile - 1;
+            for (int i = i0 + slice * R; i < i1; i += S * R) {
+                real wa[Wn], wb[Wn];
+                const real *pa = series + (i - la[0] - (kThetaTile - 1) - lo), *pb = series + (i - lb[0] - (kThetaTile - 1) - lo);
+#pragma unroll
+                for (int m = 0; m < Wn; m++) { wb[m] = pb[m]; wa[m] = rhs ? series[i - lo + min(m, R - 1)] : pa[m]; }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if (i + r >= i1) break;
+#pragma unroll
+                    for (int u = 0; u < kThetaTile; u++) {
+                        if (rhs && u > 0) break;
+                        const real su = rhs ? wa[r] : wa[r - u + kThetaTile - 1];       // s_{i+r-la[u]}
+#pragma unroll
+                        for (int v = 0; v < kThetaTile; v++) {
+                            const real prod = su * wb[r - v + kThetaTile - 1];           // val_type product
+                            acc[u][v] += (double)prod;                                 // double accumulate
+                        }
+                    }
+                }
+            }
+        } else if (live) {
             const int nrow = rhs ? 1 : kThetaTile;
             for (int i = i0 + slice; i < i1; i += S) {
                 real sa[kThetaTile], sb[kThetaTile];
