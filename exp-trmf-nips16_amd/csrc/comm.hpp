@@ -4,16 +4,22 @@
 //   SelfComm      world == 1: nothing to do.
 //   RcclComm      one process per GPU, RCCL over xGMI.  librccl is dlopen()ed on first use so a
 //                 single-GPU caller never loads it, and so that a process that already holds an
-//                 RCCL (e.g. through torch.distributed) shares that copy.  Uneven blocks are
-//                 gathered as `world` grouped ncclBroadcast calls (in place, root = owner): on a
-//                 fully connected xGMI node each is one direct write per peer link.
+//                 RCCL (e.g. through torch.distributed) shares that copy.  Uneven blocks travel as ONE
+//                 ncclAllGather of equal slots: every rank copies its block into its slot of a staging
+//                 buffer (slot = largest block), the slots are gathered in place, and a small kernel
+//                 moves the other ranks' blocks to where they belong -- all links of the fully
+//                 connected xGMI node carry data at once.  TRMF_RCCL_GATHER=broadcast selects the
+//                 earlier form instead (`world` grouped in-place ncclBroadcast calls, root = owner).
 //   CallbackComm  host-staged gather through a caller-supplied function (tests drive it with
-//                 torch.distributed/gloo; also usable where RCCL is unavailable).
+//                 torch.distributed/gloo; also usable where RCCL is unavailable).  Same slot staging
+//                 and unpack kernel as RcclComm, so two ranks on one GPU exercise them.
 #pragma once
 
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstring>
+#include <deque>
 #include <vector>
 
 #include "../../include/trmf_abi.h"
@@ -32,6 +38,75 @@ struct Comm {
     virtual int group_end() { return 0; }
 };
 
+// ---- equal-slot staging shared by the communicators -----------------------------------------------
+constexpr int kMaxWorld = 64;
+struct GatherOffsets { uint64_t off[kMaxWorld + 1]; };
+// block (x, r): bytes [off[r], off[r+1]) of the result come from slot r of the staging buffer; VEC bytes per thread
+template <typename V>
+__global__ __launch_bounds__(256) void gather_unpack_kernel(const unsigned char *__restrict__ stage,
+                                                            unsigned char *__restrict__ dbuf, GatherOffsets o,
+                                                            uint64_t slot, int rank) {
+    const int r = blockIdx.y;
+    if (r == rank) return;
+    const uint64_t n = (o.off[r + 1] - o.off[r]) / sizeof(V);
+    const V *src = reinterpret_cast<const V *>(stage + (uint64_t)r * slot);
+    V *dst = reinterpret_cast<V *>(dbuf + o.off[r]);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
+}
+struct StagePool {
+    struct Buf { unsigned char *p; size_t cap; bool busy; hipStream_t last; };
+    std::deque<Buf> bufs;                    // stable addresses: gathers of an open group keep pointers into it
+    ~StagePool() { for (Buf &b : bufs) (void)hipFree(b.p); }
+    Buf *acquire(size_t bytes, hipStream_t stream) {
+        for (Buf &b : bufs)
+            if (!b.busy && b.cap >= bytes) {
+                if (b.last != stream && hipStreamSynchronize(b.last) != hipSuccess) { set_error("stream synchronisation failed"); return nullptr; }
+                b.last = stream;             // reuse on one stream is ordered by the stream itself
+                return &b;
+            }
+        Buf b{nullptr, (bytes + 4095) / 4096 * 4096, false, stream};
+        if (hipMalloc((void **)&b.p, b.cap) != hipSuccess) { set_error("hipMalloc of a gather staging buffer failed"); return nullptr; }
+        bufs.push_back(b);
+        return &bufs.back();
+    }
+};
+struct StagedGather {                       // one gather between pack and unpack
+    unsigned char *dbuf; GatherOffsets o; uint64_t slot; StagePool::Buf *buf; hipStream_t stream;
+};
+inline uint64_t gather_slot_bytes(const uint64_t *off, int world) {
+    uint64_t slot = 0;
+    for (int r = 0; r < world; r++) slot = std::max<uint64_t>(slot, off[r + 1] - off[r]);
+    return (slot + 15) / 16 * 16;
+}
+inline int gather_pack(StagedGather &g, void *dbuf, const uint64_t *off, int rank, int world, StagePool &pool, hipStream_t stream) {
+    if (world > kMaxWorld) { set_error("more ranks than the staged gather supports"); return kFail; }
+    g.dbuf = (unsigned char *)dbuf; g.slot = gather_slot_bytes(off, world); g.stream = stream;
+    for (int r = 0; r <= world; r++) g.o.off[r] = off[r];
+    g.buf = nullptr;
+    if (g.slot == 0) return 0;                  // nothing anywhere: the callers stop here
+    g.buf = pool.acquire(g.slot * world, stream);
+    if (!g.buf) return kFail;
+    const uint64_t mine = off[rank + 1] - off[rank];
+    if (mine) TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + (uint64_t)rank * g.slot, g.dbuf + off[rank], mine, hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+inline int gather_unpack(const StagedGather &g, int rank, int world) {
+    uint64_t align = (uint64_t)(uintptr_t)g.dbuf, most = 0;
+    for (int r = 0; r <= world; r++) align |= g.o.off[r];
+    for (int r = 0; r < world; r++) if (r != rank) most = std::max<uint64_t>(most, g.o.off[r + 1] - g.o.off[r]);
+    if (most == 0) return 0;
+    const int vec = (align % 16 == 0) ? 16 : (align % 8 == 0) ? 8 : (align % 4 == 0) ? 4 : 1;
+    const dim3 grid((unsigned)std::min<uint64_t>(1024, (most / vec + 255) / 256), (unsigned)world);
+    switch (vec) {
+        case 16: hipLaunchKernelGGL(gather_unpack_kernel<uint4>, grid, dim3(256), 0, g.stream, g.buf->p, g.dbuf, g.o, g.slot, rank); break;
+        case 8: hipLaunchKernelGGL(gather_unpack_kernel<uint64_t>, grid, dim3(256), 0, g.stream, g.buf->p, g.dbuf, g.o, g.slot, rank); break;
+        case 4: hipLaunchKernelGGL(gather_unpack_kernel<uint32_t>, grid, dim3(256), 0, g.stream, g.buf->p, g.dbuf, g.o, g.slot, rank); break;
+        default: hipLaunchKernelGGL(gather_unpack_kernel<unsigned char>, grid, dim3(256), 0, g.stream, g.buf->p, g.dbuf, g.o, g.slot, rank); break;
+    }
+    TRMF_HIP_CHECK(hipGetLastError());
+    return 0;
+}
+
 struct SelfComm : Comm {
     int allgatherv(void *, const uint64_t *, hipStream_t) override { return 0; }
 };
@@ -40,19 +115,24 @@ struct CallbackComm : Comm {
     trmf_allgatherv_fn fn = nullptr;
     void *ctx = nullptr;
     std::vector<unsigned char> host;
+    StagePool pool;
     int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) override {
-        const uint64_t total = off[world];
+        StagedGather g;
+        if (gather_pack(g, dbuf, off, rank, world, pool, stream)) return kFail;
+        if (g.slot == 0) return 0;
+        const uint64_t total = g.slot * world, mine = off[rank + 1] - off[rank];
         if (host.size() < total) host.resize(total);
-        const uint64_t b0 = off[rank], b1 = off[rank + 1];
-        if (b1 > b0)
-            TRMF_HIP_CHECK(hipMemcpyAsync(host.data() + b0, (char *)dbuf + b0, b1 - b0, hipMemcpyDeviceToHost, stream));
+        std::vector<uint64_t> eq(world + 1);
+        for (int r = 0; r <= world; r++) eq[r] = (uint64_t)r * g.slot;
+        if (mine)
+            TRMF_HIP_CHECK(hipMemcpyAsync(host.data() + eq[rank], g.buf->p + eq[rank], mine, hipMemcpyDeviceToHost, stream));
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        if (fn(host.data(), off, world, ctx) != 0) { set_error("allgatherv callback failed"); return kFail; }
+        if (fn(host.data(), eq.data(), world, ctx) != 0) { set_error("allgatherv callback failed"); return kFail; }
         for (int r = 0; r < world; r++) {
             if (r == rank || off[r + 1] == off[r]) continue;
-            TRMF_HIP_CHECK(hipMemcpyAsync((char *)dbuf + off[r], host.data() + off[r], off[r + 1] - off[r],
-                                          hipMemcpyHostToDevice, stream));
+            TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + eq[r], host.data() + eq[r], off[r + 1] - off[r], hipMemcpyHostToDevice, stream));
         }
+        if (gather_unpack(g, rank, world)) return kFail;
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -66,6 +146,7 @@ struct RcclApi {
     int (*CommInitRank)(CommT *, int, UniqueId, int) = nullptr;
     int (*CommDestroy)(CommT) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int /*dtype*/, int /*root*/, CommT, hipStream_t) = nullptr;
+    int (*AllGather)(const void *, void *, size_t /*count per rank*/, int /*dtype*/, CommT, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -85,6 +166,7 @@ struct RcclApi {
         CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
         CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
         Broadcast = (decltype(Broadcast))sym("ncclBroadcast");
+        AllGather = (decltype(AllGather))sym("ncclAllGather");
         GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
         GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
         GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
@@ -107,24 +189,48 @@ struct RcclComm : Comm {
         rccl_api().CommDestroy(comm);
         if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
     }
-    int group_begin() override { return rccl_api().GroupStart() == 0 ? 0 : kFail; }
+    StagePool pool;
+    std::vector<StagedGather> pending;       // gathers issued inside a group: unpacked after ncclGroupEnd
+    bool in_group = false;
+    const bool by_broadcast = [] { const char *e = getenv("TRMF_RCCL_GATHER"); return e && e[0] == 'b'; }();
+    int group_begin() override {
+        if (rccl_api().GroupStart() != 0) return kFail;
+        in_group = true;
+        return 0;
+    }
     int group_end() override {
         const int rc = rccl_api().GroupEnd();
+        in_group = false;
+        int bad = 0;
+        for (const StagedGather &g : pending) { if (rc == 0 && gather_unpack(g, rank, world)) bad = 1; g.buf->busy = false; }
+        pending.clear();
         if (rc != 0) { set_error(std::string("RCCL group failed: ") + rccl_api().GetErrorString(rc)); return kFail; }
-        return 0;
+        return bad ? kFail : 0;
     }
     int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) override {
         RcclApi &api = rccl_api();
         constexpr int kNcclInt8 = 0;                     // ncclInt8 / ncclChar
-        int rc = api.GroupStart();
+        if (by_broadcast) return allgatherv_broadcast(dbuf, off, stream);
+        // equal slots, one collective: in place in the staging buffer (send = own slot of the receive buffer)
+        StagedGather g;
+        if (gather_pack(g, dbuf, off, rank, world, pool, stream)) return kFail;
+        if (g.slot == 0) return 0;
+        const int rc = api.AllGather(g.buf->p + (uint64_t)rank * g.slot, g.buf->p, g.slot, kNcclInt8, comm, stream);
+        if (rc != 0) { set_error(std::string("RCCL all-gather failed: ") + api.GetErrorString(rc)); return kFail; }
+        if (in_group) { g.buf->busy = true; pending.push_back(g); return 0; }    // the collective starts at ncclGroupEnd
+        return gather_unpack(g, rank, world);
+    }
+    int allgatherv_broadcast(void *dbuf, const uint64_t *off, hipStream_t stream) {
+        RcclApi &api = rccl_api();
+        constexpr int kNcclInt8 = 0;
+        int rc = in_group ? 0 : api.GroupStart();
         for (int r = 0; r < world && rc == 0; r++) {
             const uint64_t bytes = off[r + 1] - off[r];
             if (bytes == 0) continue;
             char *p = (char *)dbuf + off[r];
             rc = api.Broadcast(p, p, bytes, kNcclInt8, r, comm, stream);
         }
-        const int rc2 = api.GroupEnd();
-        if (rc == 0) rc = rc2;
+        if (!in_group) { const int rc2 = api.GroupEnd(); if (rc == 0) rc = rc2; }
         if (rc != 0) { set_error(std::string("RCCL all-gather failed: ") + api.GetErrorString(rc)); return kFail; }
         return 0;
     }

@@ -12,6 +12,7 @@ for p in (os.path.join(ROOT, 'exp-trmf-nips16_amd'), os.path.join(ROOT, 'oracle'
 
 SHAPES = {
     'small': dict(n=900, T=400, k=12, nlag=4, density=0.06),
+    'odd': dict(n=701, T=353, k=5, nlag=3, density=0.08),
     'c4': dict(n=3000, T=1200, k=40, nlag=16, density=0.04),       # BASELINE config 4's rank and lag set, scaled down
 }
 

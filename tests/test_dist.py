@@ -42,12 +42,15 @@ def test_gloo_world2_sharded_fsolve_matches_unsharded():
 
 
 @pytest.mark.gpu
-def test_two_ranks_one_gpu_match_single_process():
+@pytest.mark.parametrize('shape', ['small', 'odd'])
+def test_two_ranks_one_gpu_match_single_process(shape):
+    """'odd': rank 5 -- Gram blocks of 100 (fp32) / 200 (fp64) bytes, so the gathered blocks start at offsets that are
+    only 4- / 8-byte aligned (the narrow paths of the unpack kernel) and every block has its own size."""
     import dist_worker
     from trmf import session, synth
     iters = 3
-    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters))
-    p, m0 = dist_worker._problem()
+    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters, shape))
+    p, m0 = dist_worker._problem(shape)
     for dtype in (np.float32, np.float64):
         name = np.dtype(dtype).name
         W0, H0, T0 = m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype))
