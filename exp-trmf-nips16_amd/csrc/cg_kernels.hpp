@@ -556,9 +556,6 @@ __device__ __forceinline__ void buffer_store_real(__amdgpu_buffer_rsrc_t rsrc, i
     }
 }
 template <int VEC> struct GramVec { real c[VEC]; };
-// aligned packs for vector LDS access (ds_read_b64 / ds_read_b128)
-template <typename T> struct alignas(16) Quad { T v[4]; };
-template <typename T, int N> struct alignas((N * sizeof(T)) % 16 == 0 ? 16 : 8) VecOf { T v[N]; };
 template <int VEC>
 __device__ __forceinline__ GramVec<VEC> gram_load(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
 #if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 1)
@@ -594,7 +591,67 @@ struct HvVecs {
     real *r_out;          // CG_*: new residual
     real *out;            // H v / gradient / H d
     const real *Bv;       // GRAD: right-hand sides
+    const real *g, *w;    // CG_*: gradient and current iterate (read by the CLOSING launch only: w_new = w + s, <g,s>)
+    real *w_new;          // CG_*: the candidate iterate (written by the closing launch)
 };
+
+// ---- per-tile partial records and the time-sharded CG ------------------------------------------
+// Every launch of the fused path leaves ONE 64-byte record per tile (tile-major, fixed order => every workgroup and
+// every rank derives bit-identical scalars from them):
+//     gradient launch      [0] AR residual^2   [1] <w,w>      [2] <g,g>      [3] w.(Gw) - 2 b.w
+//     CG launch `it`       [0] <d,Hd>          [1] <r,Hd>     [2] <Hd,Hd>
+//     the CLOSING launch   [4] <g,s>           [5] <s,r>      [6] <s,s>      (w_new = w + s is written there too)
+//     plain launch (H s)   [0] AR residual^2   [1] <s,s>      [2] <s,Hs>
+// The records of a launch live in a MESSAGE buffer of `world` equal slots; slot r holds the records of rank r's tiles
+// followed by the rank's EDGE rows -- the first and the last midx rows of its timestamp block of up to three vectors
+// (d, r, H d of a CG launch; g of the gradient launch; s of the closing launch).  With one rank there is one slot and
+// no edges.  With several ranks every rank runs the tiles of its own contiguous block of timestamps (the Hessian is
+// block-diagonal per timestamp, trmf.cpp:269-288; the AR stencil reaches midx rows, trmf.cpp:125-149; the CG needs
+// three scalars per step, rf_tron.h:460-501): after each launch the slots are exchanged (one in-place all-gather of
+// the message, Comm::allgather_slots) and halo_unpack_kernel copies the neighbours' edge rows to their natural rows
+// of the local vectors, where the next launch stages them exactly as on one GPU.
+constexpr int kRecDoubles = 8;
+constexpr int kEdgeVecs = 3;
+struct TileShard {
+    int rank, world;
+    int tile0, ntiles;        // this rank's tiles [tile0, tile0 + ntiles)   (grid of every launch)
+    int nbt, tpr;             // tiles of the whole problem, tiles per slot (= nbt with one rank)
+    int row_b, row_e;         // this rank's timestamps [row_b, row_e)
+    unsigned slot_dbl;        // doubles per slot (records + edges, 16-byte multiple)
+    unsigned edge_off_dbl;    // offset of the edge rows within a slot, in doubles
+};
+template <bool SHARD>
+__device__ __forceinline__ size_t rec_index(const TileShard &sh, int t) {
+    if constexpr (!SHARD) return (size_t)t * kRecDoubles;
+    else {
+        const int r = t / sh.tpr;
+        return (size_t)r * sh.slot_dbl + (size_t)(t - r * sh.tpr) * kRecDoubles;
+    }
+}
+// edge rows of this rank's slot: [side: first rows / last rows][vector][midx * KP]
+__device__ __forceinline__ real *edge_base(double *msg, const TileShard &sh, int rank) {
+    return reinterpret_cast<real *>(msg + (size_t)rank * sh.slot_dbl + sh.edge_off_dbl);
+}
+// The neighbours' edge rows -> their natural rows of the local vectors (rows [row_b - midx, row_b) from the LAST rows of
+// rank - 1, rows [row_e, row_e + midx) from the FIRST rows of rank + 1).  by_parity: the message is msg0 or msg1 by
+// XState::r_parity (the closing launch's message, whose vector 0 is the step s).
+__global__ __launch_bounds__(256) void halo_unpack_kernel(const double *__restrict__ msg0, const double *__restrict__ msg1,
+                                                          const XState *__restrict__ st, int by_parity, TileShard sh,
+                                                          int edgeN /* midx * KP */, int KP, int nvec,
+                                                          real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
+    const double *msg = (by_parity && st->r_parity) ? msg1 : msg0;
+    real *dst[kEdgeVecs] = {v0, v1, v2};
+    for (int side = 0; side < 2; side++) {
+        const int nb = side == 0 ? sh.rank - 1 : sh.rank + 1;          // neighbour
+        if (nb < 0 || nb >= sh.world) continue;
+        // left neighbour: its LAST rows (edge side 1) land below row_b; right neighbour: its FIRST rows (side 0) at row_e
+        const real *src = reinterpret_cast<const real *>(msg + (size_t)nb * sh.slot_dbl + sh.edge_off_dbl) +
+                          (size_t)(side == 0 ? 1 : 0) * kEdgeVecs * edgeN;
+        const size_t row0 = side == 0 ? (size_t)sh.row_b * KP - edgeN : (size_t)sh.row_e * KP;
+        for (int v = 0; v < nvec; v++)
+            for (int e = blockIdx.x * 256 + threadIdx.x; e < edgeN; e += gridDim.x * 256) dst[v][row0 + e] = src[(size_t)v * edgeN + e];
+    }
+}
 
 // Workgroup b -> tile, such that the workgroups an XCD receives (b % 8 == x on gfx950's round-robin dispatch) own one
 // contiguous range of tiles.  A bijection on [0, n) for every n; changes only which workgroup does which tile.
@@ -605,13 +662,14 @@ __device__ __forceinline__ int xcd_contiguous_tile(int b, int n) {
     return x * base + min(x, extra) + i;
 }
 
-template <int MODE, int KQ>
-__global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, int np_in,
+template <int MODE, int KQ, bool SHARD>
+__global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,
                                                          const uint32_t *__restrict__ lag_set,
                                                          const real *__restrict__ theta,
                                                          const real *__restrict__ G,
-                                                         double *__restrict__ Pbase, int TI) {
+                                                         const double *__restrict__ rec_in, double *__restrict__ rec_out,
+                                                         int TI) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
     constexpr bool GRAD = MODE == HV_GRAD;
@@ -625,8 +683,9 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch; speed only, never correctness), so
     // workgroups of one XCD take CONSECUTIVE tiles -- the halo rows a tile reads (its neighbours' r, d, H d of the
     // previous launch) were then written through the same XCD's L2
-    const int tile = xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
+    const int tile = (SHARD ? sh.tile0 : 0) + xcd_contiguous_tile((int)blockIdx.x, (int)gridDim.x);
     const int i0 = tile * TI, i1 = min(i0 + TI, T);          // one tile per workgroup
+    const int np_in = sh.nbt;                                // records of the previous launch: every tile of the problem
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
     real *rn = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
@@ -659,20 +718,19 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     const bool early = MODE == HV_CG_STEP && np_in <= 256 * kEarlyPartials;
     double pq[3][kEarlyPartials];
     if (MODE == HV_CG_STEP && early) {
-        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
 #pragma unroll
         for (int m = 0; m < kEarlyPartials; m++) {
-            const int i = min(tid + 256 * m, np_in - 1);
+            const double *rec = rec_in + rec_index<SHARD>(sh, min(tid + 256 * m, np_in - 1));
 #pragma unroll
-            for (int a3 = 0; a3 < 3; a3++) pq[a3][m] = Pp[(size_t)a3 * p.pstride + i];
+            for (int a3 = 0; a3 < 3; a3++) pq[a3][m] = rec[a3];
         }
     }
     if (MODE == HV_CG_FIRST) {
         // f, |g|, tolerances from the gradient launch's partials (rf_tron.h:154-169, 424-439)
         double ar2 = 0, vv = 0, gg = 0, lq = 0;
         for (int i = tid; i < np_in; i += 256) {
-            ar2 += Pbase[P_AR * (size_t)p.pstride + i]; vv += Pbase[P_VV * (size_t)p.pstride + i];
-            gg += Pbase[P_DOT * (size_t)p.pstride + i]; lq += Pbase[P_LQ * (size_t)p.pstride + i];
+            const double *rec = rec_in + rec_index<SHARD>(sh, i);
+            ar2 += rec[0]; vv += rec[1]; gg += rec[2]; lq += rec[3];
         }
         block_allsum3(ar2, vv, gg, smem);
         lq = block_allsum(lq, smem);
@@ -763,7 +821,6 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     __builtin_amdgcn_sched_barrier(0);                      // keep the requests above everything that follows
 
     if (MODE == HV_CG_STEP) {
-        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
         double dHd = 0, rHd = 0, HH = 0;
         if (early) {
 #pragma unroll
@@ -771,7 +828,8 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                 if (tid + 256 * m < np_in) { dHd += pq[0][m]; rHd += pq[1][m]; HH += pq[2][m]; }
         } else {
             for (int i = tid; i < np_in; i += 256) {
-                dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i];
+                const double *rec = rec_in + rec_index<SHARD>(sh, i);
+                dHd += rec[0]; rHd += rec[1]; HH += rec[2];
             }
         }
         block_allsum3(dHd, rHd, HH, smem);
@@ -792,9 +850,66 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         }
     }
 
+    const uint32_t own_n = (uint32_t)((i1 - i0) * KP);
+    // time-sharded CG: does this tile hold any of the rank's first / last midx rows (which the neighbours stage as halo)?
+    const int edgeN = Hh * KP;
+    const bool edge_tile = SHARD && edgeN > 0 && (i0 < sh.row_b + Hh || i1 > sh.row_e - Hh);
+    real *edges = SHARD ? edge_base(rec_out, sh, sh.rank) : nullptr;
+    auto edge_put = [&](int vec, int ge /* element of the T x KP vector, an own row of this tile */, real x) {
+        const uint32_t lo = (uint32_t)(ge - sh.row_b * KP), hi = (uint32_t)(ge - (sh.row_e - Hh) * KP);
+        if (lo < (uint32_t)edgeN) edges[(size_t)vec * edgeN + lo] = x;
+        if (hi < (uint32_t)edgeN) edges[(size_t)(kEdgeVecs + vec) * edgeN + hi] = x;
+    };
+    if (CG && stopped) {
+        // The CLOSING launch (the stop test fired at the top of iteration `it`, or `it` is the iteration cap): s and r of the
+        // last completed iteration are finalised for the tile's own rows, and what used to be a separate pass over the
+        // vectors happens here as well -- w_new = w + s and the per-tile sums <g,s>, <s,r>, <s,s> of the acceptance test
+        // (rf_tron.h:183-190).  The gradient and the iterate are only read by this one launch of the solve.
+        const __amdgpu_buffer_rsrc_t g_own = buffer_rsrc(a.g + (size_t)i0 * KP, own_bytes);
+        const __amdgpu_buffer_rsrc_t w_own = buffer_rsrc(a.w + (size_t)i0 * KP, own_bytes);
+        const __amdgpu_buffer_rsrc_t wn_own = buffer_rsrc(a.w_new + (size_t)i0 * KP, own_bytes);
+        double gs = 0, srr = 0, ss = 0;
+        auto closing = [&](int e, real x, real rx, real hx, real sx, real gx, real wx) {
+            const int eo = e - Hh * KP;
+            if ((uint32_t)eo >= own_n) return;
+            real rnew, snew;
+            if (MODE == HV_CG_FIRST) { rnew = -x; snew = 0; }              // the gradient already met the tolerance: s = 0
+            else { snew = fma(alpha, x, sx); rnew = fma(nalpha, hx, rx); } // rf_tron.h:461, 489-490
+            buffer_store_real(s_rsrc, eo * sz, snew);
+            buffer_store_real(ro_rsrc, eo * sz, rnew);
+            buffer_store_real(wn_own, eo * sz, wx + snew);                 // rf_tron.h:183-184
+            gs += (double)gx * (double)snew; srr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
+            if (edge_tile) edge_put(0, i0 * KP + eo, snew);
+        };
+        real gv[kHvOperandRegs], wv[kHvOperandRegs];
+#pragma unroll
+        for (int m = 0; m < kHvOperandRegs; m++) {
+            gv[m] = MODE == HV_CG_FIRST ? vr[m] : buffer_load_real(g_own, obyte0 + 256 * m * sz);
+            wv[m] = buffer_load_real(w_own, obyte0 + 256 * m * sz);
+        }
+#pragma unroll
+        for (int m = 0; m < kHvOperandRegs; m++)
+            closing(tid + 256 * m, vr[m], MODE == HV_CG_STEP ? rv[m] : real(0), MODE == HV_CG_STEP ? hr[m] : real(0),
+                    MODE == HV_CG_STEP ? sr[m] : real(0), gv[m], wv[m]);
+#pragma nounroll
+        for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256) {
+            const int vb = vbyte0 + (e - tid) * sz, ob = obyte0 + (e - tid) * sz;
+            const real x = buffer_load_real(v_rsrc, vb);
+            closing(e, x, MODE == HV_CG_STEP ? buffer_load_real(r_rsrc, vb) : real(0),
+                    MODE == HV_CG_STEP ? buffer_load_real(h_rsrc, vb) : real(0),
+                    MODE == HV_CG_STEP ? buffer_load_real(s_rsrc, ob) : real(0),
+                    MODE == HV_CG_FIRST ? x : buffer_load_real(g_own, ob), buffer_load_real(w_own, ob));
+        }
+        block_allsum3(gs, srr, ss, smem);
+        if (tid == 0) {
+            double *rec = rec_out + rec_index<SHARD>(sh, tile);
+            rec[4] = gs; rec[5] = srr; rec[6] = ss;
+        }
+        return;
+    }
+
     // (1) operand rows -> LDS (zeros outside [0,T) stay zeros through every update below)
     double ar2 = 0, vv = 0, dot = 0, lq = 0, rhd = 0, hh = 0;
-    const uint32_t own_n = (uint32_t)((i1 - i0) * KP);
     auto operand = [&](int e, real x, real rx, real hx, real sx) {
         const int eo = e - Hh * KP;                                        // index within the tile's own rows
         if (CG) {
@@ -808,7 +923,10 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             buffer_store_real(s_rsrc, eo * sz, snew);                      // all three dropped outside the own rows
             buffer_store_real(ro_rsrc, eo * sz, rnew);
             buffer_store_real(do_rsrc, eo * sz, x);
-            if ((uint32_t)eo < own_n) rn[eo] = rnew;
+            if ((uint32_t)eo < own_n) {
+                rn[eo] = rnew;
+                if (edge_tile) { edge_put(0, i0 * KP + eo, x); edge_put(1, i0 * KP + eo, rnew); }
+            }
         } else {
             if ((uint32_t)eo < own_n) vv += (double)x * (double)x;
         }
@@ -825,7 +943,6 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                 MODE == HV_CG_STEP ? buffer_load_real(h_rsrc, vb) : real(0),
                 MODE == HV_CG_STEP ? buffer_load_real(s_rsrc, ob) : real(0));
     }
-    if (CG && stopped) return;                              // s and r are final; no further product
 #if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 2)
     const bool ar_on = false;
 #else
@@ -972,6 +1089,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                 }
                 const real oc = (real)(od[c] + ac);
                 a.out[(size_t)i * KP + tpos[c]] = oc;
+                if (edge_tile && (CG || GRAD)) edge_put(CG ? 2 : 0, i * KP + tpos[c], oc);   // H d of a CG launch / the gradient
                 dot += (double)(GRAD ? oc : x[c]) * (double)oc;      // <g,g> for the gradient, <v,Hv> otherwise
                 if (CG) {
                     rhd += (double)rn[rr * KP + tpos[c]] * (double)oc;       // <r,Hd>
@@ -980,23 +1098,17 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             }
         }
     }
+    double *rec = rec_out + rec_index<SHARD>(sh, tile);
     if (CG) {
         block_allsum3(dot, rhd, hh, smem);
-        if (threadIdx.x == 0) {
-            double *Po = Pbase + (size_t)(P_CG0 + 3 * (it & 1)) * p.pstride;
-            Po[tile] = dot; Po[(size_t)p.pstride + tile] = rhd; Po[2 * (size_t)p.pstride + tile] = hh;
-        }
+        if (threadIdx.x == 0) { rec[0] = dot; rec[1] = rhd; rec[2] = hh; }
         return;
     }
     block_allsum3(ar2, vv, dot, smem);
-    if (GRAD) {
-        lq = block_allsum(lq, smem);
-        if (threadIdx.x == 0) Pbase[P_LQ * (size_t)p.pstride + tile] = lq;
-    }
+    if (GRAD) lq = block_allsum(lq, smem);
     if (threadIdx.x == 0) {
-        Pbase[P_AR * (size_t)p.pstride + tile] = ar2;
-        Pbase[P_VV * (size_t)p.pstride + tile] = vv;
-        Pbase[P_DOT * (size_t)p.pstride + tile] = dot;
+        rec[0] = ar2; rec[1] = vv; rec[2] = dot;             // gradient launch: <g,g>; plain launch: <v,Hv>
+        if (GRAD) rec[3] = lq;
     }
 }
 
@@ -1103,6 +1215,57 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
         // parameters of trmf.cpp:603-606 run a pure CG pass): delta0 = |g|, first iteration min(delta, |s|), then the
         // update by the ratio of actual to predicted reduction
         double delta = fmin(st->gnorm, snorm);
+        const double curv = fnew - f - gs;
+        const double alpha = curv <= 0 ? 4.0 : fmax(0.25, -0.5 * (gs / curv));
+        if (actred < 1e-4 * prered) delta = fmin(fmax(alpha, 0.25) * snorm, 0.5 * delta);
+        else if (actred < 0.25 * prered) delta = fmax(0.25 * delta, fmin(alpha * snorm, 0.5 * delta));
+        else if (actred < 0.75 * prered) delta = fmax(0.25 * delta, fmin(alpha * snorm, 4.0 * delta));
+        else delta = fmax(delta, fmin(alpha * snorm, 4.0 * delta));
+        st->delta = delta;
+        if (log_x) {                                    // iteration record written here: no copies on the stream
+            log_x->f = f; log_x->fnew = fnew; log_x->gnorm = st->gnorm; log_x->cg_rnorm = sqrt(rho);
+            log_x->actred = actred; log_x->prered = prered; log_x->gs = gs; log_x->sr = sr;
+            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0; log_x->delta = delta;
+            log_norms[0] = log_norms[1] = log_norms[2] = -1.0;      // ||.||^2 lines are off in this mode
+        }
+    }
+}
+
+// ---- acceptance test and commit of the fused path: sums of the per-tile records -----------------------------------
+// <g,s>, <s,r>, <s,s> come from the closing launch's message (msg0 / msg1 by XState::r_parity), <s,Hs> from the plain
+// launch's; with several ranks a rank commits its own timestamps [row_b, row_e) (the rows of W are all-gathered next).
+__global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msg0,
+                                                          const double *__restrict__ msg1, const double *__restrict__ msgP,
+                                                          TileShard sh, int sharded, const real *__restrict__ w_new,
+                                                          real *__restrict__ w, XState *__restrict__ log_x,
+                                                          double *__restrict__ log_norms) {
+    __shared__ double smem[256];
+    const double *msgC = st->r_parity ? msg1 : msg0;
+    double gs_d = 0, sr_d = 0, ss_d = 0, sHs = 0;
+    for (int i = threadIdx.x; i < sh.nbt; i += 256) {
+        const size_t ri = sharded ? rec_index<true>(sh, i) : rec_index<false>(sh, i);
+        gs_d += msgC[ri + 4]; sr_d += msgC[ri + 5]; ss_d += msgC[ri + 6]; sHs += msgP[ri + 2];
+    }
+    block_allsum3(gs_d, sr_d, ss_d, smem);
+    sHs = block_allsum(sHs, smem);
+    const double gs = (double)(real)gs_d, sr = (double)(real)sr_d;          // BLAS dots in val_type (rf_tron.h:186-187)
+    const double snorm = sqrt((double)(real)ss_d);
+    const double rho = (double)(real)st->rho_hist[st->cg_iter];
+    const double f = st->f;
+    const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190
+    const double actred = -(gs + 0.5 * sHs);                                 // = f - f(w+s), exactly
+    const double fnew = f - actred;
+    const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
+    if (accept) {
+        const size_t e0 = (size_t)sh.row_b * p.KP, e1 = (size_t)sh.row_e * p.KP;
+        for (size_t e = e0 + (size_t)blockIdx.x * 256 + threadIdx.x; e < e1; e += (size_t)gridDim.x * 256) w[e] = w_new[e];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {          // fields no block reads in this kernel
+        st->fnew = fnew; st->gs = gs; st->sr = sr;
+        st->prered = prered; st->actred = actred;
+        st->accepted = accept ? 1 : 0;
+        st->cg_rnorm = sqrt(rho);
+        double delta = fmin(st->gnorm, snorm);          // trust-region bound of the TRON line: see accept_kernel
         const double curv = fnew - f - gs;
         const double alpha = curv <= 0 ? 4.0 : fmax(0.25, -0.5 * (gs / curv));
         if (actred < 1e-4 * prered) delta = fmin(fmax(alpha, 0.25) * snorm, 0.5 * delta);

@@ -36,6 +36,9 @@ struct Comm {
     // Several gathers issued between group_begin() and group_end() may be fused into one transfer round.
     virtual int group_begin() { return 0; }
     virtual int group_end() { return 0; }
+    // Gather in place with EQUAL slots: rank r owns bytes [r * slot, (r + 1) * slot) of dbuf.  No staging, no unpack:
+    // the per-step exchange of the time-sharded CG (one message slot per rank: tile records + edge rows).
+    virtual int allgather_slots(void *dbuf, size_t slot_bytes, hipStream_t stream) = 0;
 };
 
 // ---- equal-slot staging shared by the communicators -----------------------------------------------
@@ -54,13 +57,17 @@ __global__ __launch_bounds__(256) void gather_unpack_kernel(const unsigned char 
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
 }
 struct StagePool {
+    // `last` is only ever COMPARED, never passed to the runtime: the pool lives in the communicator, which outlives the
+    // sessions (and their streams) it serves, so the handle may belong to a stream that no longer exists.
     struct Buf { unsigned char *p; size_t cap; bool busy; hipStream_t last; };
     std::deque<Buf> bufs;                    // stable addresses: gathers of an open group keep pointers into it
     ~StagePool() { for (Buf &b : bufs) (void)hipFree(b.p); }
     Buf *acquire(size_t bytes, hipStream_t stream) {
         for (Buf &b : bufs)
             if (!b.busy && b.cap >= bytes) {
-                if (b.last != stream && hipStreamSynchronize(b.last) != hipSuccess) { set_error("stream synchronisation failed"); return nullptr; }
+                // another stream used the buffer last (a previous session under this communicator): wait for the whole
+                // device -- set-up path, once per session -- instead of synchronising a handle that may be destroyed
+                if (b.last != stream && hipDeviceSynchronize() != hipSuccess) { set_error("device synchronisation failed"); return nullptr; }
                 b.last = stream;             // reuse on one stream is ordered by the stream itself
                 return &b;
             }
@@ -109,6 +116,7 @@ inline int gather_unpack(const StagedGather &g, int rank, int world) {
 
 struct SelfComm : Comm {
     int allgatherv(void *, const uint64_t *, hipStream_t) override { return 0; }
+    int allgather_slots(void *, size_t, hipStream_t) override { return 0; }
 };
 
 struct CallbackComm : Comm {
@@ -133,6 +141,22 @@ struct CallbackComm : Comm {
             TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + eq[r], host.data() + eq[r], off[r + 1] - off[r], hipMemcpyHostToDevice, stream));
         }
         if (gather_unpack(g, rank, world)) return kFail;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int allgather_slots(void *dbuf, size_t slot, hipStream_t stream) override {
+        if (slot == 0 || world == 1) return 0;
+        const uint64_t total = (uint64_t)slot * world;
+        if (host.size() < total) host.resize(total);
+        std::vector<uint64_t> eq(world + 1);
+        for (int r = 0; r <= world; r++) eq[r] = (uint64_t)r * slot;
+        unsigned char *d = (unsigned char *)dbuf;
+        TRMF_HIP_CHECK(hipMemcpyAsync(host.data() + eq[rank], d + eq[rank], slot, hipMemcpyDeviceToHost, stream));
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        if (fn(host.data(), eq.data(), world, ctx) != 0) { set_error("allgatherv callback failed"); return kFail; }
+        if (rank > 0) TRMF_HIP_CHECK(hipMemcpyAsync(d, host.data(), eq[rank], hipMemcpyHostToDevice, stream));
+        if (rank + 1 < world)
+            TRMF_HIP_CHECK(hipMemcpyAsync(d + eq[rank + 1], host.data() + eq[rank + 1], total - eq[rank + 1], hipMemcpyHostToDevice, stream));
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -211,6 +235,13 @@ struct RcclComm : Comm {
         RcclApi &api = rccl_api();
         constexpr int kNcclInt8 = 0;                     // ncclInt8 / ncclChar
         if (by_broadcast) return allgatherv_broadcast(dbuf, off, stream);
+        // Equal slots cost world x (largest block) of staging per gather in flight.  With a very skewed partition (row
+        // counts of an nnz-balanced split can differ widely) that can be several times the gathered data itself: beyond
+        // 4x the payload (and 64 MiB) the in-place form -- one broadcast per owner, no extra memory -- is used instead.
+        {
+            const uint64_t stage = gather_slot_bytes(off, world) * (uint64_t)world, payload = off[world] - off[0];
+            if (stage > 4 * payload && stage > (64ull << 20)) return allgatherv_broadcast(dbuf, off, stream);
+        }
         // equal slots, one collective: in place in the staging buffer (send = own slot of the receive buffer)
         StagedGather g;
         if (gather_pack(g, dbuf, off, rank, world, pool, stream)) return kFail;
@@ -219,6 +250,13 @@ struct RcclComm : Comm {
         if (rc != 0) { set_error(std::string("RCCL all-gather failed: ") + api.GetErrorString(rc)); return kFail; }
         if (in_group) { g.buf->busy = true; pending.push_back(g); return 0; }    // the collective starts at ncclGroupEnd
         return gather_unpack(g, rank, world);
+    }
+    int allgather_slots(void *dbuf, size_t slot, hipStream_t stream) override {
+        if (slot == 0) return 0;
+        RcclApi &api = rccl_api();
+        const int rc = api.AllGather((unsigned char *)dbuf + (size_t)rank * slot, dbuf, slot, /* ncclInt8 */ 0, comm, stream);
+        if (rc != 0) { set_error(std::string("RCCL all-gather failed: ") + api.GetErrorString(rc)); return kFail; }
+        return 0;
     }
     int allgatherv_broadcast(void *dbuf, const uint64_t *off, hipStream_t stream) {
         RcclApi &api = rccl_api();

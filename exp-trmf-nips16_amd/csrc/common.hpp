@@ -33,6 +33,10 @@ __host__ __device__ constexpr int padded_rank(int k) { return ((k + kTile - 1) /
 __host__ __device__ constexpr int colpos(int t, int NT) { return NT * (t & 15) + (t >> 4); }
 __host__ __device__ constexpr int collog(int p, int NT) { return kTile * (p % NT) + p / NT; }
 
+// aligned packs for vector LDS access (ds_read_b64 / ds_read_b128)
+template <typename T> struct alignas(16) Quad { T v[4]; };
+template <typename T, int N> struct alignas((N * sizeof(T)) % 16 == 0 ? 16 : 8) VecOf { T v[N]; };
+
 #define TRMF_HIP_CHECK(expr)                                                                  \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \

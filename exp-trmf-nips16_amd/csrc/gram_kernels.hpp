@@ -549,6 +549,208 @@ __global__ __launch_bounds__(256, TRMF_GRID_WAVES) void fsolve_grid_kernel(const
 }
 #endif  // !TRMF_F32
 
+
+// ---- F-solve, fp64, factorisation IN the accumulator layout (round 3; config 5's kernel) --------------------------------
+// fsolve_grid_kernel moves the Gram out of the MFMA accumulators (LDS staging into an 8 x 8 lane grid) and eliminates
+// one pivot at a time: 64 LDS round trips, ~1250 + 290 FMAs, 350 multiplies and 950 LDS instructions per rank-64
+// system.  Here the k x k system never leaves the registers the Gram was accumulated in:
+//
+//   * v_mfma_f64_16x16x4_f64 keeps row (lane>>4) + 4 r, column lane & 15 of a 16 x 16 tile in register r.  FOUR
+//     CONSECUTIVE rows 4 r0 .. 4 r0 + 3 of a tile row are therefore register r0 of the four 16-lane groups -- which is
+//     exactly the K = 4 operand layout of the same instruction (lane group = contraction index).  A panel of four
+//     pivot rows R'_p (after the elimination inside the panel) updates every trailing tile with ONE MFMA,
+//         A22[16 ti + m][16 tj + n] -= sum_p (R'_p[16 ti + m] / d_p) R'_p[16 tj + n],
+//     whose B operand IS the pivot-row register of tile column tj and whose A operand is the same register of tile
+//     column ti scaled by -1/d_p: no data movement at all.  80 MFMAs replace the ~1250 FMAs + their broadcasts.
+//   * Inside a panel (4 rows x <= 64 columns) the four lane groups hold one row each; the rows are transposed through a
+//     small LDS record per column (80-byte pitch: conflict-free 16-byte accesses) so that lane l owns COLUMN l with all
+//     four rows: the 4 x 4 diagonal block is read by every lane (broadcast) and factorised redundantly (L D L^T,
+//     v_rcp_f64 + Newton), each lane eliminates its column (6 FMAs), forms the scaled copy, and the lane groups read
+//     their row back as the two MFMA operands.  One write + one read per tile column each way.
+//   * The right-hand side lives one element per lane (lane l = row l) and follows with four FMAs per panel (the
+//     multipliers of its row are the scaled column the lane has just computed); lane j0 -- whose own column is the
+//     panel's first pivot column and needs no work -- eliminates the panel's four rhs entries.
+//   * Back substitution, column oriented, in the same lane = row layout: the strict upper triangle of one tile column
+//     at a time is staged column-major in LDS (rows at and below the diagonal as exact zeros, so finished lanes are
+//     never touched and the solution is simply y / d at the end); a step is multiply, v_readlane, one conflict-free LDS
+//     read and one FMA.
+// posv('U') of the reference (rf_matrix.h:3008-3014) and this differ by rounding only (fp64 gate 1e-6, tests/).
+#if !defined(TRMF_F32)
+#ifndef TRMF_MFMA_WAVES
+#define TRMF_MFMA_WAVES 2
+#endif
+#ifndef TRMF_RCP_NEWTON
+#define TRMF_RCP_NEWTON 2
+#endif
+__device__ __forceinline__ double recip_pivot(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+#pragma unroll
+    for (int i = 0; i < TRMF_RCP_NEWTON; i++) { const double e = fma(-d, r, 1.0); r = fma(r, e, r); }
+    return r;
+}
+__host__ __device__ constexpr int upper_tile_index(int ti, int tj, int NT) { return ti * NT - ti * (ti - 1) / 2 + (tj - ti); }
+
+template <int NT, int KMAX>
+__global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
+                                                                          const uint32_t *__restrict__ idx,
+                                                                          const real *__restrict__ val,
+                                                                          const real *__restrict__ X,
+                                                                          real *__restrict__ F, uint32_t row_begin,
+                                                                          uint32_t row_end, int k, real lambda,
+                                                                          uint32_t zero_row) {
+    static_assert(sizeof(real) == 8, "the in-accumulator F-solve is the fp64 path");
+    constexpr int KP = kTile * NT, NPAN = KMAX / 4;
+    constexpr int CP = 10;                                // doubles per column record: R'0 S0 R'1 S1 R'2 S2 R'3 S3 + 2 pad
+    constexpr int FIN = (KP + 1) * CP;                    // after the records of columns 0..KP-1 and of the rhs: (z'_q, 1/d_q) x 4
+    constexpr int RP = KP + 2;                            // row pitch of the back substitution's column buffer
+    constexpr int SCR = (FIN + 8 > kTile * RP) ? FIN + 8 : kTile * RP;
+    __shared__ __attribute__((aligned(16))) real scr_s[4][SCR];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
+    if (row >= row_end) return;                         // wave-uniform; no block barrier below
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
+    if (p0 == p1) return;                               // trmf.cpp:374: empty rows stay untouched
+    real *ps = scr_s[wave];
+    typedef typename Mfma16<real>::acc_t acc_t;
+    typedef VecOf<real, 2> pair_t;
+
+    GramState<NT> st;
+    st.clear();
+    {
+        real nowq[NT];
+#pragma unroll
+        for (int q = 0; q < NT; q++) nowq[q] = 0;
+        gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
+                                               SingleRowStream{4u * kRingDepth}, [](int) {});
+    }
+    // right-hand side: fold the 4 lane groups, then lane l = 16 q + c keeps b[l]
+    real y = 0, dinv = 1;
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+        real v = st.b[q];
+        v += __shfl_xor(v, 16, kWave);
+        v += __shfl_xor(v, 32, kWave);
+        if (g == q) y = v;
+    }
+    // + lambda on the diagonal (trmf.cpp:393); pad rows get a unit diagonal: their steps are no-ops
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (c == g + 4 * r) st.acc[upper_tile_index(ti, ti, NT)][r] += (kTile * ti + c < k) ? lambda : real(1);
+
+    // ---- elimination, four pivots per step ----
+    static_for<NPAN>([&](auto Pn) {
+        constexpr int pn = decltype(Pn)::value, tp = pn >> 2, r0 = pn & 3, j0 = 4 * pn;
+        // (1) the panel's rows (lane group g holds row j0 + g) -> column records; the four rhs entries -> record KP
+#pragma unroll
+        for (int tj = tp; tj < NT; tj++) ps[(kTile * tj + c) * CP + g] = st.acc[upper_tile_index(tp, tj, NT)][r0];
+        if ((unsigned)(lane - j0) < 4u) ps[KP * CP + (lane - j0)] = y;
+        wave_lds_sync();
+        // (2) the 4 x 4 diagonal block (same addresses in every lane: broadcast reads), (3) its L D L^T
+        const real *pc = ps + j0 * CP;
+        const real P00 = pc[0];
+        real P01 = pc[CP], P11 = pc[CP + 1];
+        real P02 = pc[2 * CP], P12 = pc[2 * CP + 1], P22 = pc[2 * CP + 2];
+        real P03 = pc[3 * CP], P13 = pc[3 * CP + 1], P23 = pc[3 * CP + 2], P33 = pc[3 * CP + 3];
+        const real i0 = recip_pivot(P00);
+        const real l10 = P01 * i0, l20 = P02 * i0, l30 = P03 * i0;
+        P11 = fma(-l10, P01, P11); P12 = fma(-l10, P02, P12); P13 = fma(-l10, P03, P13);
+        P22 = fma(-l20, P02, P22); P23 = fma(-l20, P03, P23); P33 = fma(-l30, P03, P33);
+        const real i1 = recip_pivot(P11);
+        const real l21 = P12 * i1, l31 = P13 * i1;
+        P22 = fma(-l21, P12, P22); P23 = fma(-l21, P13, P23); P33 = fma(-l31, P13, P33);
+        const real i2 = recip_pivot(P22);
+        const real l32 = P23 * i2;
+        P33 = fma(-l32, P23, P33);
+        const real i3 = recip_pivot(P33);
+        // (4) lane l owns column l (lane j0: the rhs column -- its own column is the first pivot column and needs nothing)
+        const bool has_col = KP == kWave || lane < KP;
+        const int col = (lane == j0 || !has_col) ? KP : lane;
+        real *rec = ps + col * CP;
+        const Quad<real> rin = *reinterpret_cast<const Quad<real> *>(rec);
+        const real R0 = rin.v[0];
+        const real R1 = fma(-l10, R0, rin.v[1]);
+        const real R2 = fma(-l21, R1, fma(-l20, R0, rin.v[2]));
+        const real R3 = fma(-l32, R2, fma(-l31, R1, fma(-l30, R0, rin.v[3])));
+        const real S0 = -(R0 * i0), S1 = -(R1 * i1), S2 = -(R2 * i2), S3 = -(R3 * i3);
+        if (has_col) {
+            *reinterpret_cast<Quad<real> *>(rec) = Quad<real>{{R0, S0, R1, S1}};
+            *reinterpret_cast<Quad<real> *>(rec + 4) = Quad<real>{{R2, S2, R3, S3}};
+        }
+        if (lane == j0) {                                // eliminated rhs entries z'_q and the pivots' reciprocals
+            *reinterpret_cast<Quad<real> *>(ps + FIN) = Quad<real>{{R0, i0, R1, i1}};
+            *reinterpret_cast<Quad<real> *>(ps + FIN + 4) = Quad<real>{{R2, i2, R3, i3}};
+        }
+        wave_lds_sync();
+        // (5) the rhs follows: rows below the panel take four FMAs with the multipliers of their row (the scaled column
+        //     the lane has just formed), the panel's rows take their final values
+        {
+            const Quad<real> f0 = *reinterpret_cast<const Quad<real> *>(ps + FIN), f1 = *reinterpret_cast<const Quad<real> *>(ps + FIN + 4);
+            const real upd = fma(S3, f1.v[2], fma(S2, f1.v[0], fma(S1, f0.v[2], fma(S0, f0.v[0], y))));
+            const int q = min(max(lane - j0, 0), 3);
+            const pair_t mine = *reinterpret_cast<const pair_t *>(ps + FIN + 2 * q);
+            const bool in_panel = (unsigned)(lane - j0) < 4u;
+            y = in_panel ? mine.v[0] : (lane > j0 + 3 ? upd : y);
+            dinv = in_panel ? mine.v[1] : dinv;
+        }
+        // (6) lane group g reads its row back: final pivot row (B operand, kept in the accumulators) and scaled copy (A operand)
+        real aop[NT];
+#pragma unroll
+        for (int tj = tp; tj < NT; tj++) {
+            const pair_t rs = *reinterpret_cast<const pair_t *>(ps + (kTile * tj + c) * CP + 2 * g);
+            st.acc[upper_tile_index(tp, tj, NT)][r0] = rs.v[0];
+            aop[tj] = rs.v[1];
+        }
+        if (c <= 4 * r0 + 3) aop[tp] = 0;                // rows at and above the panel are final: the update leaves them alone
+        wave_lds_sync();
+        // (7) trailing update on the matrix pipe
+#pragma unroll
+        for (int ti = tp; ti < NT; ti++)
+#pragma unroll
+            for (int tj = ti; tj < NT; tj++) {
+                constexpr int dummy = 0; (void)dummy;
+                acc_t &C = st.acc[upper_tile_index(ti, tj, NT)];
+                C = Mfma16<real>::mma(aop[ti], st.acc[upper_tile_index(tp, tj, NT)][r0], C);
+            }
+    });
+
+    // ---- back substitution (D L^T) x = z', column oriented, lane = row ----
+    static_for<NT>([&](auto Tr) {
+        constexpr int tt = NT - 1 - decltype(Tr)::value;
+        if constexpr (kTile * tt < KMAX) {
+            // strict upper triangle of tile column tt, column-major: cb[n * RP + row]; rows at / below the diagonal and the
+            // sixteen rows beyond this tile column as exact zeros (lanes whose unknown is final are never touched)
+#pragma unroll
+            for (int ti = 0; ti <= tt; ti++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    real v = st.acc[upper_tile_index(ti, tt, NT)][r];
+                    if (ti == tt && g + 4 * r >= c) v = 0;
+                    ps[c * RP + kTile * ti + g + 4 * r] = v;
+                }
+            if constexpr (tt + 1 < NT) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) ps[c * RP + kTile * (tt + 1) + g + 4 * r] = 0;
+            }
+            wave_lds_sync();
+            static_for<kTile>([&](auto Nr) {
+                constexpr int n = kTile - 1 - decltype(Nr)::value, t = kTile * tt + n;
+                if constexpr (t < KMAX && t > 0) {
+                    const real xt = lane_bcast(y * dinv, t);
+                    const real cv = (KP == kWave || lane < KP) ? ps[n * RP + lane] : real(0);
+                    y = fma(-cv, xt, y);
+                }
+            });
+            wave_lds_sync();
+        }
+    });
+    if (lane < k) F[(size_t)row * KP + colpos(lane, NT)] = y * dinv;
+}
+#endif  // !TRMF_F32
+
 #if defined(TRMF_F32)
 // ---- F-solve, quad form (fp32): one wavefront per FOUR item rows ------------------------------------
 // The O(k^3) part of the solve is a chain of rank-1 updates whose operands must be broadcast across

@@ -33,25 +33,41 @@ namespace trmf {
 
 std::shared_ptr<Comm> active_comm();   // trmf_abi.hip
 
+// Stream that zero-fills of fresh buffers are ordered on (the owning session's solver stream, set for the duration of
+// every entry point that allocates).  hipMemset runs on the NULL stream and may return before the fill has executed, and
+// the solver's stream is non-blocking (never ordered against the NULL stream): filling ON the solver stream orders the
+// fill before every later user without a device-wide wait per buffer (round 2: one hipDeviceSynchronize per buffer,
+// ~25 of them per create / append_rows).
+inline hipStream_t &fill_stream() { static thread_local hipStream_t s = nullptr; return s; }
+struct FillStreamScope {
+    hipStream_t prev;
+    explicit FillStreamScope(hipStream_t s) : prev(fill_stream()) { fill_stream() = s; }
+    ~FillStreamScope() { fill_stream() = prev; }
+};
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0, cap = 0;       // elements in use / allocated (a buffer that shrinks or regrows within cap is reused)
     DevBuf() {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
-    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; cap = 0; } }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
     int alloc(size_t count, bool zero = true) {
-        release();
+        const size_t want = std::max<size_t>(count, 1);
+        if (!p || want > cap) {
+            release();
+            TRMF_HIP_CHECK(hipMalloc((void **)&p, want * sizeof(T)));
+            cap = want;
+        }
         n = count;
-        TRMF_HIP_CHECK(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
         if (zero) {
-            // hipMemset runs on the NULL stream and may return before the fill has executed; the solver's stream is
-            // non-blocking (never ordered against the NULL stream), so the fill must be complete before anyone on that
-            // stream can touch the buffer.  Allocation is set-up work: a device-wide wait is fine here.
-            TRMF_HIP_CHECK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
-            TRMF_HIP_CHECK(hipDeviceSynchronize());
+            if (fill_stream()) TRMF_HIP_CHECK(hipMemsetAsync(p, 0, want * sizeof(T), fill_stream()));
+            else {              // no session stream known: fill on the NULL stream and wait for it
+                TRMF_HIP_CHECK(hipMemset(p, 0, want * sizeof(T)));
+                TRMF_HIP_CHECK(hipDeviceSynchronize());
+            }
         }
         return 0;
     }
@@ -101,7 +117,19 @@ struct TrmfSessionImpl {
     std::vector<PhaseEvents> events;
     static constexpr int kEventRing = 64;
     int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
-    int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), grid
+    int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), tiles of the problem
+    // fused path: per-tile records of each launch (cg_kernels.hpp "per-tile partial records") in three message buffers:
+    // CG launches of even / odd iteration, gradient + plain launch.  tsh: the one-rank view (one slot, every tile);
+    // tsh_rank: this rank's block of tiles when the CG is sharded over time (ts_possible).
+    DevBuf<double> xmsg[3];
+    TileShard tsh{}, tsh_rank{};
+    std::vector<uint64_t> tbounds;            // tile-aligned timestamp partition of the time-sharded CG
+    bool ts_possible = false;
+    enum { kTsOff = 0, kTsOn = 1, kTsMeasure = 2 };
+    int ts_mode = kTsMeasure, ts_calls = 0, cg_pred = 4;
+    bool ts_last = false;                     // the last X-solve ran time-sharded
+    float ts_ms[2] = {0, 0};                  // X phase, replicated / time-sharded (the measured calls)
+    hipEvent_t ts0 = nullptr, ts1 = nullptr;
     int ar_TI = 64, nbar = 1;                 // unfused path: timestamps per ar_tile_kernel workgroup, its partial-sum slots
     DevBuf<real> arbase;                      // lambdaI*v + lambdaAR*AR'(v) between ar_tile_kernel and apply_kernel
     XParams xp{};
@@ -111,7 +139,7 @@ struct TrmfSessionImpl {
             hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.x1, e.lv1};
             for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
         }
-        for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2}) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2, ts0, ts1}) if (ev) (void)hipEventDestroy(ev);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -181,10 +209,11 @@ struct TrmfSessionImpl {
         if (const char *e = getenv("TRMF_FSOLVE")) {
             const std::string m(e);
             use_quad = use_quad && m != "wave";
-            use_grid = use_grid && m != "wave";
+            if (sizeof(real) == 8) { use_mfma = m != "wave" && m != "grid"; use_grid = m == "grid"; }
         }
         if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
         TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        FillStreamScope fill(stream);
 
         dense = Y->type != TRMF_SPARSE;
         if (!dense) {
@@ -225,7 +254,7 @@ struct TrmfSessionImpl {
             hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
             for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
-        for (hipEvent_t *ev : {&gx0, &gx1, &gx2, &fs0, &fs1, &fs2}) TRMF_HIP_CHECK(hipEventCreate(ev));
+        for (hipEvent_t *ev : {&gx0, &gx1, &gx2, &fs0, &fs1, &fs2, &ts0, &ts1}) TRMF_HIP_CHECK(hipEventCreate(ev));
         if (gramx_times.alloc((size_t)2 * comm->world)) return kFail;
         if (comm->world == 1) { gramx_mode = kGramxShard; fs_mode = kShardOn; }     // nothing to decide
         if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
@@ -313,6 +342,7 @@ struct TrmfSessionImpl {
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
         }
+        if (setup_tile_messages()) return kFail;
         {   // unfused path: timestamps per AR tile.  One workgroup per CU (LDS); a tile costs ~(TI + 2 midx) staged rows,
             // (TI + midx) residual rows and TI output rows, and the grid runs in ceil(tiles * column groups / CUs) rounds:
             // take the tile count with the cheapest schedule among those whose halo fits the 150 KB LDS budget (tiles of at
@@ -362,6 +392,43 @@ struct TrmfSessionImpl {
         return 0;
     }
 
+    // Message buffers of the fused path and the tile partition of the time-sharded CG: rank r owns
+    // the tiles [r * tpr, (r + 1) * tpr) -- a contiguous block of timestamps -- and needs, per launch, the other
+    // ranks' tile records (three scalars per CG step) and midx rows of halo from each neighbour.  Possible when every
+    // rank holds at least one tile and at least midx timestamps (halo rows then come from the direct neighbours only).
+    int setup_tile_messages() {
+        tsh = TileShard{};
+        tsh.rank = 0; tsh.world = 1; tsh.tile0 = 0; tsh.ntiles = nbt; tsh.nbt = nbt; tsh.tpr = std::max(nbt, 1);
+        tsh.row_b = 0; tsh.row_e = T; tsh.slot_dbl = (unsigned)nbt * kRecDoubles; tsh.edge_off_dbl = tsh.slot_dbl;
+        tsh_rank = tsh;
+        ts_possible = false;
+        tbounds.assign(comm->world + 1, (uint64_t)T);
+        tbounds[0] = 0;
+        size_t doubles = (size_t)std::max(nbt, 1) * kRecDoubles;
+        const int W_ = comm->world;
+        if (tile_TI > 0 && W_ > 1 && !full) {
+            const int tpr = (nbt + W_ - 1) / W_;
+            const long long last_rows = (long long)T - (long long)(W_ - 1) * tpr * tile_TI;
+            if ((long long)(W_ - 1) * tpr < nbt && (long long)tpr * tile_TI >= midx && last_rows >= std::max(midx, 1)) {
+                ts_possible = true;
+                const size_t edge_bytes = (size_t)2 * kEdgeVecs * midx * KP * sizeof(real);
+                tsh_rank.rank = comm->rank; tsh_rank.world = W_; tsh_rank.tpr = tpr;
+                tsh_rank.tile0 = comm->rank * tpr; tsh_rank.ntiles = std::min(nbt, (comm->rank + 1) * tpr) - tsh_rank.tile0;
+                tsh_rank.row_b = tsh_rank.tile0 * tile_TI; tsh_rank.row_e = std::min(T, (tsh_rank.tile0 + tsh_rank.ntiles) * tile_TI);
+                tsh_rank.edge_off_dbl = (unsigned)tpr * kRecDoubles;
+                tsh_rank.slot_dbl = tsh_rank.edge_off_dbl + (unsigned)((edge_bytes + 15) / 16 * 2);
+                for (int r = 1; r < W_; r++) tbounds[r] = (uint64_t)std::min<long long>(T, (long long)r * tpr * tile_TI);
+                doubles = std::max(doubles, (size_t)W_ * tsh_rank.slot_dbl);
+            }
+        }
+        for (auto &m : xmsg) if (m.alloc(doubles)) return kFail;
+        if (const char *e = getenv("TRMF_CG")) {
+            if (e[0] == 't') ts_mode = kTsOn;                  // timeshard
+            else if (e[0] == 'r') ts_mode = kTsOff;            // replicate
+        }
+        return 0;
+    }
+
     // ---- per-series affine transform of a resident dense Y (trmf_session_set_series_transform) -------------------------
     // rolling_validate(transform=True) -- the paper scripts' setting -- refits a NormalizedTransform on every growing
     // prefix (trmf.py:82-96, 237-249), which rescales EVERY entry of Y.  The session therefore keeps the raw matrix and
@@ -372,6 +439,7 @@ struct TrmfSessionImpl {
     bool has_transform = false;
     int set_series_transform(const real *a, const real *b) {
         if (!dense) { set_error("set_series_transform: needs a dense Y (missing == 0)"); return kFail; }
+        FillStreamScope fill(stream);
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         if (Yraw.n != (size_t)T * n) {              // first call: the resident copy is still the raw matrix
             if (has_transform) { set_error("set_series_transform: raw matrix lost"); return kFail; }
@@ -412,14 +480,22 @@ struct TrmfSessionImpl {
         if ((uint64_t)(T0 + Tn + 1) >= (1ull << 24) || (uint64_t)(T0 + Tn + 1) * KP * sizeof(real) > 0xffffffffull ||
             nnz + Yn->nnz >= (1ull << 32)) { set_error("append_rows: problem would exceed 32-bit device indices"); return kFail; }
         if (Tn <= 0) return 0;
+        FillStreamScope fill(stream);
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         const int T1 = T0 + Tn;
+        // Failure-atomic: everything new is built in locals (device buffers, host pointer arrays, sums) and swapped into
+        // the session only after every allocation, copy and kernel of the step has succeeded; a failed call leaves the
+        // session exactly as it was.
+        std::vector<uint64_t> new_row_ptr, new_col_ptr;
+        uint64_t new_nnz = nnz;
+        double new_ysq = ysq_acc;
+        DevBuf<uint32_t> ptr2, idx2, cptr2, cidx2; DevBuf<real> val2, cval2, tn2, nt2, raw2, W2;
         if (!dense) {
             const uint64_t nz0 = nnz, nzn = Yn->nnz, nz1 = nz0 + nzn;
             // CSR: old rows keep their place, the block's rows follow
-            for (int i = 1; i <= Tn; i++) host_row_ptr.push_back(nz0 + Yn->row_ptr[i]);
-            DevBuf<uint32_t> ptr2, idx2; DevBuf<real> val2;
-            if (upload_ptr32(ptr2, (const size_t *)host_row_ptr.data(), (size_t)T1 + 1) || idx2.alloc(nz1, false) || val2.alloc(nz1, false)) return kFail;
+            new_row_ptr = host_row_ptr;
+            for (int i = 1; i <= Tn; i++) new_row_ptr.push_back(nz0 + Yn->row_ptr[i]);
+            if (upload_ptr32(ptr2, (const size_t *)new_row_ptr.data(), (size_t)T1 + 1) || idx2.alloc(nz1, false) || val2.alloc(nz1, false)) return kFail;
             TRMF_HIP_CHECK(hipMemcpyAsync(idx2.p, Yr_idx.p, nz0 * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
             TRMF_HIP_CHECK(hipMemcpyAsync(val2.p, Yr_val.p, nz0 * sizeof(real), hipMemcpyDeviceToDevice, stream));
             if (nzn) {
@@ -427,9 +503,10 @@ struct TrmfSessionImpl {
                 TRMF_HIP_CHECK(hipMemcpyAsync(val2.p + nz0, Yn->val_t, nzn * sizeof(real), hipMemcpyHostToDevice, stream));
             }
             // CSC: column j = its old entries, then the block's entries of that column (timestamps shifted by T0)
+            new_col_ptr = host_col_ptr;
             std::vector<uint32_t> np32((size_t)n + 1);
-            for (int j = 0; j <= n; j++) { host_col_ptr[j] += Yn->col_ptr[j]; np32[j] = (uint32_t)host_col_ptr[j]; }
-            DevBuf<uint32_t> cptr2, cidx2, wptr, widx; DevBuf<real> cval2, wval;
+            for (int j = 0; j <= n; j++) { new_col_ptr[j] += Yn->col_ptr[j]; np32[j] = (uint32_t)new_col_ptr[j]; }
+            DevBuf<uint32_t> wptr, widx; DevBuf<real> wval;
             if (cptr2.upload(np32.data(), np32.size()) || cidx2.alloc(nz1, false) || cval2.alloc(nz1, false) ||
                 upload_ptr32(wptr, Yn->col_ptr, (size_t)n + 1) || widx.upload(Yn->row_idx, nzn) || wval.upload((const real *)Yn->val, nzn))
                 return kFail;
@@ -437,39 +514,42 @@ struct TrmfSessionImpl {
                                wval.p, cptr2.p, cidx2.p, cval2.p, n, (uint32_t)T0);
             TRMF_HIP_CHECK(hipGetLastError());
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-            Yr_ptr.swap(ptr2); Yr_idx.swap(idx2); Yr_val.swap(val2);
-            Yc_ptr.swap(cptr2); Yc_idx.swap(cidx2); Yc_val.swap(cval2);
-            nnz = nz1;
-            if (device_sum_squares(Yr_val.p, nnz, &ysq_acc)) return kFail;
+            new_nnz = nz1;
+            if (device_sum_squares(val2.p, new_nnz, &new_ysq)) return kFail;
         } else {
             std::vector<real> blk;
-            ysq_acc += dense_rows_to_rowmajor(Yn, blk);
-            DevBuf<real> tn2, nt2;
+            new_ysq += dense_rows_to_rowmajor(Yn, blk);
             if (tn2.alloc((size_t)T1 * n, false) || nt2.alloc((size_t)T1 * n, false)) return kFail;
             TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p, Yd_tn.p, (size_t)T0 * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
             TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p + (size_t)T0 * n, blk.data(), blk.size() * sizeof(real), hipMemcpyHostToDevice, stream));
             if (has_transform) {                        // the block is RAW data: grow the raw copy, re-derive below
-                DevBuf<real> raw2;
                 if (raw2.alloc((size_t)T1 * n, false)) return kFail;
                 TRMF_HIP_CHECK(hipMemcpyAsync(raw2.p, Yraw.p, (size_t)T0 * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
                 TRMF_HIP_CHECK(hipMemcpyAsync(raw2.p + (size_t)T0 * n, blk.data(), blk.size() * sizeof(real), hipMemcpyHostToDevice, stream));
-                TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-                Yraw.swap(raw2);
             }
             launch_transpose(tn2.p, T1, n, nt2.p);
-            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-            Yd_tn.swap(tn2); Yd_nt.swap(nt2);
-            nnz = (uint64_t)T1 * n;
+            TRMF_HIP_CHECK(hipGetLastError());
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));      // blk is a local: its copies must have left the host
+            new_nnz = (uint64_t)T1 * n;
         }
         {   // W: T0 rows kept, Tn rows rolled out by the AR model, one all-zero row at the end
-            DevBuf<real> W2;
             if (W2.alloc((size_t)(T1 + 1) * KP)) return kFail;
             TRMF_HIP_CHECK(hipMemcpyAsync(W2.p, W.p, (size_t)T0 * KP * sizeof(real), hipMemcpyDeviceToDevice, stream));
             hipLaunchKernelGGL(latent_forecast_kernel, dim3(1), dim3(64), 0, stream, W2.p, T0, T1, KP, NT, k, lag_set.p, nlag, theta.p);
             TRMF_HIP_CHECK(hipGetLastError());
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-            W.swap(W2);
         }
+        // ---- commit ----
+        if (!dense) {
+            Yr_ptr.swap(ptr2); Yr_idx.swap(idx2); Yr_val.swap(val2);
+            Yc_ptr.swap(cptr2); Yc_idx.swap(cidx2); Yc_val.swap(cval2);
+            host_row_ptr.swap(new_row_ptr); host_col_ptr.swap(new_col_ptr);
+        } else {
+            Yd_tn.swap(tn2); Yd_nt.swap(nt2);
+            if (has_transform) Yraw.swap(raw2);
+        }
+        W.swap(W2);
+        nnz = new_nnz; ysq_acc = new_ysq;
         T = T1;
         if (dense && has_transform && apply_series_transform()) return kFail;   // current coefficients over the grown raw matrix
         set_trYTY();
@@ -505,6 +585,15 @@ struct TrmfSessionImpl {
 #endif
         return 0;
     }
+    template <int NT_, int KMAX_> int launch_fsolve_mfma(uint32_t rb, uint32_t re) {
+        const uint32_t rows = re - rb;
+        if (rows == 0) return 0;
+#if !defined(TRMF_F32)
+        hipLaunchKernelGGL((fsolve_mfma_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
+                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
+#endif
+        return 0;
+    }
     template <int NT_, int KMAX_> int launch_fsolve_quad(uint32_t rb, uint32_t re) {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
@@ -530,9 +619,10 @@ struct TrmfSessionImpl {
 #endif
         return 0;
     }
-    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64: one system per wavefront, block-cyclic over an
-    // 8 x 8 lane grid (fsolve_grid_kernel); TRMF_FSOLVE=wave: one system per wavefront, one column per lane
-    bool use_quad = sizeof(real) == 4, use_grid = sizeof(real) == 8;
+    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64: one system per wavefront, factorised in the MFMA
+    // accumulator layout (fsolve_mfma_kernel).  TRMF_FSOLVE=grid: the round-2 fp64 kernel (block-cyclic over an 8 x 8
+    // lane grid); TRMF_FSOLVE=wave: one system per wavefront, one column per lane
+    bool use_quad = sizeof(real) == 4, use_grid = false, use_mfma = sizeof(real) == 8;
     // X-side Gram build across ranks: sharded rows + all-gather of G (64 MB at config 3) pays only when a
     // rank's share of the gather is cheaper than the rows it no longer computes -- true on 8 GPUs, not on 2.
     // First call measures (kernel and gather time of every rank, exchanged through the communicator so that
@@ -556,6 +646,7 @@ struct TrmfSessionImpl {
             default: set_error("unsupported rank"); return kFail;                    \
         }
         if (use_quad) { TRMF_FSOLVE_SWITCH(launch_fsolve_quad) }
+        else if (use_mfma) { TRMF_FSOLVE_SWITCH(launch_fsolve_mfma) }
         else if (use_grid) { TRMF_FSOLVE_SWITCH(launch_fsolve_grid) }
         else { TRMF_FSOLVE_SWITCH(launch_fsolve) }
 #undef TRMF_FSOLVE_SWITCH
@@ -632,7 +723,18 @@ struct TrmfSessionImpl {
             hipLaunchKernelGGL((loss_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
                                Yr_val.p, H.p, Wv, lossrow.p, rb, re, (uint32_t)n);
     }
-    int gram_x() {
+    int gram_x(bool timeshard = false) {
+        if (timeshard) {            // time-sharded CG: a rank only ever reads the Grams / right-hand sides of its own tiles
+            const uint32_t rb = (uint32_t)tsh_rank.row_b, re = (uint32_t)tsh_rank.row_e;
+            switch (NT) {
+                case 1: launch_gram_x<1>(rb, re); break;
+                case 2: launch_gram_x<2>(rb, re); break;
+                case 3: launch_gram_x<3>(rb, re); break;
+                default: launch_gram_x<4>(rb, re); break;
+            }
+            TRMF_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         if (!cg_shard && gramx_mode == kGramxMeasure && gramx_calls == 2 && gramx_decide()) return kFail;   // second call measured, see fsolve()
         const bool replicate = gramx_mode == kGramxReplicate && !cg_shard;
         const bool measure = gramx_mode == kGramxMeasure && !cg_shard && gramx_calls == 1;
@@ -769,11 +871,12 @@ struct TrmfSessionImpl {
 
     // ---- X-solve (trmf.cpp:665-674 -> rf_tron.h:134-254) -----------------------------------------------
     // Fused path (the AR halo fits LDS): hv_tile_kernel in its four roles, one launch per CG iteration.
-    template <int MODE> void launch_hv_tile(const HvVecs &a, int it, int last) {
+    template <int MODE, bool SHARD> void launch_hv_tile_as(const HvVecs &a, int it, int last, const double *rec_in, double *rec_out) {
         const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
-#define TRMF_LAUNCH_HV_KQ(KQ)                                                                           \
-        hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ>), dim3(nbt), dim3(256), lds, stream, xp, xstate.p, a, nbt, it, last,  \
-                           lag_set.p, theta.p, Gmat(), partials.p, tile_TI)
+        const TileShard &sh = SHARD ? tsh_rank : tsh;
+#define TRMF_LAUNCH_HV_KQ(KQ)                                                                                        \
+        hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ, SHARD>), dim3(sh.ntiles), dim3(256), lds, stream, xp, xstate.p, a, sh, it, last,  \
+                           lag_set.p, theta.p, Gmat(), rec_in, rec_out, tile_TI)
         switch (hv_kq(k) / 8) {
             case 1: TRMF_LAUNCH_HV_KQ(8); break;
             case 2: TRMF_LAUNCH_HV_KQ(16); break;
@@ -785,6 +888,88 @@ struct TrmfSessionImpl {
             default: TRMF_LAUNCH_HV_KQ(64); break;
         }
 #undef TRMF_LAUNCH_HV_KQ
+    }
+    template <int MODE> void launch_hv_tile(bool shard, const HvVecs &a, int it, int last, const double *rec_in, double *rec_out) {
+        if (shard) launch_hv_tile_as<MODE, true>(a, it, last, rec_in, rec_out);
+        else launch_hv_tile_as<MODE, false>(a, it, last, rec_in, rec_out);
+    }
+    // time-sharded CG: exchange the slots of a message (tile records + edge rows of every rank), then copy the
+    // neighbours' edge rows of up to three vectors to their natural rows of the local vectors
+    int exchange_message(DevBuf<double> &m) {
+        return comm->allgather_slots(m.p, (size_t)tsh_rank.slot_dbl * sizeof(double), stream);
+    }
+    void unpack_halo(const double *m0, const double *m1, int by_parity, int nvec, real *v0, real *v1, real *v2) {
+        const int edgeN = midx * KP;
+        if (edgeN == 0) return;
+        hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, m0, m1,
+                           xstate.p, by_parity, tsh_rank, edgeN, KP, nvec, v0, v1, v2);
+    }
+    // The fused X-solve: gradient launch, CG launches (one per iteration, the closing one also forms w_new and the sums
+    // of the acceptance test), plain launch H s, accept.  shard: every launch runs this rank's tiles only and is
+    // followed by the exchange of its message; the host then follows the CG's progress (the stop is detected on the
+    // device) so that no exchange is issued for an iteration that will not run: it enqueues as many iterations as the
+    // previous solve needed, reads XState::stop_it back, and goes on two at a time.  All ranks derive identical scalars
+    // from identical records, so they take identical decisions (the collectives match).
+    int xsolve_fused(bool shard, int maxcg, XState *log_x, double *log_n) {
+        real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
+        double *mg = xmsg[2].p, *mc[2] = {xmsg[0].p, xmsg[1].p};
+        HvVecs a{};
+        a.v = W.p; a.out = g.p; a.Bv = Bv.p;
+        launch_hv_tile<HV_GRAD>(shard, a, 0, 0, nullptr, mg);                  // gradient, <g,g>, AR/ridge sums
+        if (shard) { if (exchange_message(xmsg[2])) return kFail; unpack_halo(mg, mg, 0, 1, g.p, nullptr, nullptr); }
+        a = HvVecs{};
+        a.v = g.p; a.s = s.p; a.d_out = dbuf[0]; a.r_out = rbuf[0]; a.out = hbuf[0];
+        a.g = g.p; a.w = W.p; a.w_new = w_new.p;
+        launch_hv_tile<HV_CG_FIRST>(shard, a, 0, 0, mg, mc[0]);                // f, |g|, cgtol; s = 0, r = d = -g; H d
+        if (shard) { if (exchange_message(xmsg[0])) return kFail; unpack_halo(mc[0], mc[0], 0, 3, dbuf[0], rbuf[0], hbuf[0]); }
+        int upto = shard ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
+        for (int it = 1; it <= maxcg; it++) {                              // launch `maxcg` only closes the last iteration
+            a.v = dbuf[(it - 1) & 1]; a.r_in = rbuf[(it - 1) & 1]; a.hd_in = hbuf[(it - 1) & 1];
+            a.d_out = dbuf[it & 1]; a.r_out = rbuf[it & 1]; a.out = hbuf[it & 1];
+            launch_hv_tile<HV_CG_STEP>(shard, a, it, it == maxcg ? 1 : 0, mc[(it - 1) & 1], mc[it & 1]);
+            if (!shard) continue;
+            if (exchange_message(xmsg[it & 1])) return kFail;
+            unpack_halo(mc[it & 1], mc[it & 1], 0, 3, dbuf[it & 1], rbuf[it & 1], hbuf[it & 1]);
+            if (it == upto && it < maxcg) {                                // has the CG stopped?  (identical on every rank)
+                int stop = kCgRunning;
+                TRMF_HIP_CHECK(hipMemcpyAsync(&stop, &xstate.p->stop_it, sizeof(int), hipMemcpyDeviceToHost, stream));
+                TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+                if (stop != kCgRunning) { cg_pred = stop; break; }
+                upto = std::min(maxcg, upto + 2);
+            } else if (it == maxcg) cg_pred = maxcg;
+        }
+        if (shard) unpack_halo(mc[0], mc[1], 1, 1, s.p, nullptr, nullptr);     // halo of s from the closing launch's message
+        a = HvVecs{};
+        a.v = s.p; a.out = hbuf[0];
+        launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs>
+        if (shard && exchange_message(xmsg[2])) return kFail;
+        const TileShard &sh = shard ? tsh_rank : tsh;
+        const int nb = (int)std::min<size_t>(kMaxPartials, ((size_t)(sh.row_e - sh.row_b) * KP + 255) / 256);
+        hipLaunchKernelGGL(accept_tile_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mc[0], mc[1], mg, sh,
+                           shard ? 1 : 0, w_new.p, W.p, log_x, log_n);
+        TRMF_HIP_CHECK(hipGetLastError());
+        if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
+        return 0;
+    }
+    // Replicated or time-sharded CG?  Measured once, like the other shard decisions: X phases 0 and 1 run replicated
+    // (the second one timed), 2 and 3 time-sharded (the second one timed); the times of every rank are exchanged and
+    // the slower rank decides.  Both forms give bit-identical iterates, so switching between iterations is free.
+    int decide_timeshard() {
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        const double mine[2] = {(double)ts_ms[0], (double)ts_ms[1]};
+        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 2 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
+        std::vector<uint64_t> off(comm->world + 1);
+        for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * sizeof mine;
+        if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<double> all((size_t)2 * comm->world);
+        TRMF_HIP_CHECK(hipMemcpy(all.data(), gramx_times.p, all.size() * sizeof(double), hipMemcpyDeviceToHost));
+        double t_rep = 0, t_ts = 0;
+        for (int r = 0; r < comm->world; r++) { t_rep = std::max(t_rep, all[2 * r]); t_ts = std::max(t_ts, all[2 * r + 1]); }
+        ts_mode = t_ts < t_rep ? kTsOn : kTsOff;
+        if (verbose && comm->rank == 0)
+            fprintf(stderr, ">> X-solve: replicated CG %.3f ms vs time-sharded %.3f ms -> %s\n", t_rep, t_ts, ts_mode == kTsOn ? "time-sharded" : "replicated");
+        return 0;
     }
     // Multi-GPU, unfused path: shard the cached-Gram product of every CG step.  It pays when the
     // rows a rank no longer streams (T k^2 s (1 - 1/N) bytes at ~4 TB/s) outweigh an all-gather of T KP s bytes per
@@ -864,36 +1049,32 @@ struct TrmfSessionImpl {
     }
     const real *Gmat() const { return full ? GSx.p : G.p; }      // shared H^T H or the per-timestamp cache
 
-    int xsolve(XState *log_x = nullptr, double *log_n = nullptr) {   // log_*: record written by accept_kernel
+    int xsolve(XState *log_x = nullptr, double *log_n = nullptr) {   // log_*: record written by the accept kernel
         XState *st = xstate.p;
         double *Pb = partials.p;
+        const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
+        const bool fused = tile_TI > 0 && maxcg <= kCgHistCap;
+        bool shard = false, timed = false;
+        if (fused && ts_possible) {
+            if (ts_mode == kTsMeasure && ts_calls == 4 && decide_timeshard()) return kFail;
+            if (ts_mode == kTsOn) shard = true;
+            else if (ts_mode == kTsMeasure) { shard = ts_calls >= 2; timed = ts_calls == 1 || ts_calls == 3; }
+            ts_calls++;
+        }
+        ts_last = shard;
+        if (timed) TRMF_HIP_CHECK(hipEventRecord(ts0, stream));
         if (full) {
             if (xprepare_full()) return kFail;                                 // b = Y H, shared Gram H^T H
         } else {
-            if (gram_x()) return kFail;                                        // G, b
+            if (gram_x(shard)) return kFail;                                   // G, b
         }
-        const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
-        if (tile_TI > 0 && maxcg <= kCgHistCap) {
-            real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
-            HvVecs a{};
-            a.v = W.p; a.out = g.p; a.Bv = Bv.p;
-            launch_hv_tile<HV_GRAD>(a, 0, 0);                                  // gradient, <g,g>, AR/ridge sums
-            a = HvVecs{};
-            a.v = g.p; a.s = s.p; a.d_out = dbuf[0]; a.r_out = rbuf[0]; a.out = hbuf[0];
-            launch_hv_tile<HV_CG_FIRST>(a, 0, 0);                              // f, |g|, cgtol; s = 0, r = d = -g; H d
-            for (int it = 1; it <= maxcg; it++) {                              // launch `maxcg` only closes the last iteration
-                a.v = dbuf[(it - 1) & 1]; a.r_in = rbuf[(it - 1) & 1]; a.hd_in = hbuf[(it - 1) & 1];
-                a.d_out = dbuf[it & 1]; a.r_out = rbuf[it & 1]; a.out = hbuf[it & 1];
-                launch_hv_tile<HV_CG_STEP>(a, it, it == maxcg ? 1 : 0);
+        if (fused) {
+            if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
+            if (timed) {
+                TRMF_HIP_CHECK(hipEventRecord(ts1, stream));
+                TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+                TRMF_HIP_CHECK(hipEventElapsedTime(&ts_ms[shard ? 1 : 0], ts0, ts1));
             }
-            hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1],
-                               w_new.p, Pb);
-            a = HvVecs{};
-            a.v = s.p; a.out = hbuf[0];
-            launch_hv_tile<HV_PLAIN>(a, 0, 0);                                 // H s, <s,Hs>
-            hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, nbt,
-                               (const double *)nullptr, w_new.p, W.p, log_x, log_n);
-            TRMF_HIP_CHECK(hipGetLastError());
             return 0;
         }
         real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};

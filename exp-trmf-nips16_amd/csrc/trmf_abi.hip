@@ -145,14 +145,12 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
         fprintf(stdout, "\n");
         fflush(stdout);
     }
-    // Quirk Q1: with warm_start == 0 the reference trains on private randomly initialised copies
-    // and the caller's arrays come back unchanged (trmf.cpp:552-558).  Reproduced as far as a caller can observe
-    // it through the arrays: the problem is validated (same diagnostics as a warm start), nothing is trained and
-    // nothing is written.  The reference's ">> iter" lines of that discarded run are not reproduced.
-    if (!warm_start) {
-        (void)validate_problem(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, missing);
-        return;
-    }
+    // Quirk Q1: with warm_start == 0 the reference rebuilds W, H and lag_val as private random
+    // matrices of matching shapes BEFORE its dimension check (trmf.cpp:547-558, 719-722), trains those and discards
+    // them: the caller's arrays come back unchanged and no "[ERR MSG]" line can appear.  Reproduced as far as a caller
+    // can observe it: nothing is validated, trained or written (the ">> iter" lines of the discarded run are not
+    // reproduced).
+    if (!warm_start) return;
     DeviceGuard guard;                               // device of this library for the call, the caller's afterwards
     TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
                                       lambdaLag, period_W, period_H, period_Lag, missing, verbose);
@@ -285,6 +283,7 @@ int32_t trmf_dist_get_unique_id(void *out_id) {
 
 int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id_bytes) {
     if (world < 1 || rank < 0 || rank >= world) { set_error("bad rank/world"); return kFail; }
+    if (world > kMaxWorld) { set_error("more ranks than the staged gather supports (64)"); return kFail; }
     DeviceGuard guard;
     if (!guard.ok) return kFail;
     RcclApi &api = rccl_api();
@@ -301,6 +300,7 @@ int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id_bytes) {
 
 int32_t trmf_dist_init_callback(int32_t rank, int32_t world, trmf_allgatherv_fn fn, void *ctx) {
     if (world < 1 || rank < 0 || rank >= world || !fn) { set_error("bad rank/world/callback"); return kFail; }
+    if (world > kMaxWorld) { set_error("more ranks than the staged gather supports (64)"); return kFail; }
     std::shared_ptr<CallbackComm> c = std::make_shared<CallbackComm>();
     c->rank = rank; c->world = world; c->fn = fn; c->ctx = ctx;
     g_comm = std::move(c);

@@ -75,9 +75,11 @@ typedef struct {
  * (trmf.cpp:647-693).  Outputs are written in place; Y and lag_set are never written.
  * Dimension/layout violations print the reference's "[ERR MSG]" lines on stderr and return
  * without touching the outputs (trmf.cpp:561-596,632-634).  warm_start == 0 reproduces the
- * reference's observable behaviour: the problem is validated, the
- * caller's arrays are not updated (the reference trains private random copies and discards
- * them; that discarded run and its ">> iter" lines are not reproduced).  `threads` is accepted
+ * reference's observable behaviour: the reference rebuilds W, H and
+ * lag_val as private random matrices of matching shapes before its dimension check
+ * (trmf.cpp:547-558), trains those and discards them -- the caller's arrays are not updated
+ * and no "[ERR MSG]" line can appear; here the call returns at once (silent, nothing written;
+ * the discarded run and its ">> iter" lines are not reproduced).  `threads` is accepted
  * and ignored (no OpenMP on the device path).
  *
  * Checks beyond the reference's (each prints one "[ERR MSG]: ..." line and returns like a
@@ -186,6 +188,7 @@ TRMF_API void trmf_session_destroy(TrmfSession *s);
 /* Rank 0: create an RCCL unique id; the caller broadcasts the bytes to all ranks
  * (e.g. with torch.distributed) and every rank passes them to trmf_dist_init. */
 TRMF_API int32_t trmf_dist_get_unique_id(void *out_id /* TRMF_UNIQUE_ID_BYTES */);
+/* world <= 64 (slots of the staged all-gather); larger worlds are refused here. */
 TRMF_API int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id /* TRMF_UNIQUE_ID_BYTES */);
 /* Host-staged communicator for tests and RCCL-less setups: `allgatherv` must gather, in place,
  * the byte ranges [offsets[r], offsets[r+1]) of `buf` owned by each rank r. Returns 0 on success. */

@@ -61,26 +61,45 @@ def cpu_sharded_fsolve(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None):
-    """Two processes on ONE GPU, host-staged all-gather over gloo: the sharded device path must give
+def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None, dtypes=('float32', 'float64')):
+    """`world` processes on ONE GPU, host-staged all-gather over gloo: the sharded device path must give
     results bit-identical across ranks and equal to the single-process run.  `env`: switches of the library
-    (e.g. TRMF_NO_HV_TILE / TRMF_CG to run the sharded Gram product of the unfused CG)."""
+    (e.g. TRMF_CG=timeshard|replicate, TRMF_NO_HV_TILE to run the sharded Gram product of the unfused CG).
+    shape 'c3full': BASELINE config 3 / 4 at its full size (100k x 10k, k=40, |L|=16)."""
     import torch.distributed as dist
     os.environ.update(env or {})
     from trmf import dist as tdist, session, synth
     from helpers import make_model
     dist.init_process_group('gloo', init_method='tcp://127.0.0.1:{}'.format(port), rank=rank, world_size=world)
     res = {}
-    for dtype in (np.float32, np.float64):
-        p, m0 = _problem(shape)
+    for name in dtypes:
+        dtype = np.dtype(name).type
+        if shape == 'c3full':
+            cfg = synth.CONFIGS['c3']
+            p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=dtype, seed=0)
+            m0 = synth.initial_model(p['Y'], p['lag_set'], cfg['k'], seed=0)
+        else:
+            p, m0 = _problem(shape)
         Y = p['Y'].astype(dtype)
         W0, H0, T0 = m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype))
         tdist.init_host_staged(dtype)
         model = make_model(W0, H0, T0, p['lag_set'])
         with session.Session(Y, model, missing=True, **synth.HYPER) as s:
             s.run(iters); st = s.stats(iters); s.download()
+        # a SECOND session under the same live communicator (its staging buffers remember the first session's stream,
+        # which no longer exists): same result
+        again = make_model(W0, H0, T0, p['lag_set'])
+        with session.Session(Y, again, missing=True, **synth.HYPER) as s:
+            s.run(iters); s.download()
+        same = bool(np.array_equal(again.W, model.W) and np.array_equal(again.H, model.H) and np.array_equal(again.lag_val, model.lag_val))
         tdist.finalize(dtype)
-        res[np.dtype(dtype).name] = (model.W.copy(), model.H.copy(), model.lag_val.copy(), [x['cg_iter'] for x in st])
+        phases = [(x['ms_F'], x['ms_F_kernel'], x['ms_X'], x['ms_LV']) for x in st]
+        if shape == 'c3full':       # the factors of the full problem stay in the worker: digests + a sample travel
+            import hashlib
+            dig = [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (model.W, model.H, model.lag_val)]
+            res[name] = (dig, None, None, [x['cg_iter'] for x in st], same, phases)
+        else:
+            res[name] = (model.W.copy(), model.H.copy(), model.lag_val.copy(), [x['cg_iter'] for x in st], same, phases)
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()

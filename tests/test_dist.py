@@ -27,9 +27,9 @@ def _spawn(fn, world, *args):
     procs = [ctx.Process(target=fn, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=600) for _ in range(1 if fn.__name__ == 'cpu_sharded_fsolve' else world)]
+    out = [q.get(timeout=1500) for _ in range(1 if fn.__name__ == 'cpu_sharded_fsolve' else world)]
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=300)
         assert p.exitcode == 0
     return out
 
@@ -58,10 +58,90 @@ def test_two_ranks_one_gpu_match_single_process(shape):
         with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
             s.run(iters); st = s.stats(iters); s.download()
         for r in (0, 1):
-            W, H, Th, cg = out[r][name]
-            # every kernel is deterministic and the CG runs replicated: bit-identical everywhere
+            W, H, Th, cg, second_session_same = out[r][name][:5]
+            # every kernel is deterministic and every rank derives the same scalars: bit-identical everywhere
             assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val)
             assert cg == [x['cg_iter'] for x in st]
+            assert second_session_same      # a second session under the same communicator (its staging pool outlives streams)
+
+
+def _single_process(p, m0, dtype, iters):
+    from trmf import session, synth
+    model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
+    with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
+        s.run(iters); st = s.stats(iters); s.download()
+    return model, [x['cg_iter'] for x in st]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,shape,mode', [(2, 'small', 'timeshard'), (2, 'odd', 'timeshard'), (2, 'c4', 'timeshard'),
+                                              (4, 'c4', 'timeshard'), (8, 'c4', 'timeshard'), (3, 'c4', 'measure'),
+                                              (4, 'c4', 'replicate')])
+def test_time_sharded_cg_matches_single_process(world, shape, mode):
+    """The CG sharded over TIME: every rank runs the tiles of its own block of timestamps, the tile
+    records (three scalars per CG step) and midx halo rows per neighbour are exchanged after every launch.  Same
+    records summed in the same order => bit-identical to the single-process run, in both precisions, for 2 / 3 / 4 / 8
+    ranks (uneven last block at 'odd'), forced (TRMF_CG=timeshard), forced off, and under the measure-once rule (which
+    runs iterations 1-2 replicated and 3-4 time-sharded, then decides: 5 iterations cover the switch both ways)."""
+    import dist_worker
+    iters = 5 if mode == 'measure' else 3
+    env = {} if mode == 'measure' else {'TRMF_CG': mode}
+    out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, shape, env))
+    p, m0 = dist_worker._problem(shape)
+    for dtype in (np.float32, np.float64):
+        name = np.dtype(dtype).name
+        model, cg1 = _single_process(p, m0, dtype, iters)
+        for r in range(world):
+            W, H, Th, cg, second_session_same = out[r][name][:5]
+            assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val), (r, name)
+            assert cg == cg1 and second_session_same
+
+
+_C3_REF = {}
+
+
+def _c3_single_process_digests(iters):
+    """W / H / Theta digests and CG counts of the single-process run of config 3 at full size (computed once)."""
+    if iters not in _C3_REF:
+        import hashlib
+        from trmf import synth
+        cfg = synth.CONFIGS['c3']
+        p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float32, seed=0)
+        m0 = synth.initial_model(p['Y'], p['lag_set'], cfg['k'], seed=0)
+        model, cg = _single_process(p, m0, np.float32, iters)
+        _C3_REF[iters] = ([hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (model.W, model.H, model.lag_val)], cg)
+    return _C3_REF[iters]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 4, 8])
+def test_config4_full_size_sharded_paths_on_one_gpu(world):
+    """BASELINE config 4 = config 3 (100k x 10k, 1 %, k=40, |L|=16, fp32) at its FULL size through the sharded ALS loop
+    with 2, 4 and 8 ranks sharing the one GPU (host-staged exchange): F rows sharded, X-side Gram rows sharded, and the
+    CG both replicated (Grams gathered) and sharded over time (tile records + halo rows exchanged per launch).  Every
+    rank's factors must be bit-identical to the single-process run (compared through SHA-256 digests: the factors of the
+    full problem stay in the workers).  The per-rank phase times are printed; they share one GPU, so only their sum over
+    ranks is meaningful here (scripts/shard_compute_times.py measures a rank's share alone)."""
+    import json
+    import os
+    import dist_worker
+    iters = 2
+    ref_dig, ref_cg = _c3_single_process_digests(iters)
+    report = {}
+    for mode in ('replicate', 'timeshard'):
+        out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c3full', {'TRMF_CG': mode, 'TRMF_FSHARD': 'shard', 'TRMF_GRAMX': 'shard'},
+                          ('float32',)))
+        for r in range(world):
+            dig, _, _, cg, second_session_same, phases = out[r]['float32']
+            assert dig == ref_dig, (mode, r)
+            assert cg == ref_cg and second_session_same
+        report[mode] = {r: out[r]['float32'][5] for r in range(world)}
+        print('config 4 full size, %d ranks on one GPU, CG %s: CG %s; last iteration per rank (ms F / F kernel / X / Theta): %s' % (
+            world, mode, ref_cg, ['%.2f/%.2f/%.2f/%.2f' % tuple(report[mode][r][-1]) for r in range(world)]))
+    root = os.environ.get('GRAFT_REPO_ROOT')
+    if root and os.path.isdir(os.path.join(root, 'gpurun_out')):
+        with open(os.path.join(root, 'gpurun_out', 'c4_one_gpu_world%d.json' % world), 'w') as fh:
+            json.dump(report, fh)
 
 
 @pytest.mark.gpu
@@ -71,7 +151,7 @@ def test_two_ranks_one_gpu_config4_shape_replicated_cg():
     import dist_worker
     from trmf import session, synth
     iters = 3
-    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters, 'c4'))
+    out = dict(_spawn(dist_worker.gpu_host_staged, 2, iters, 'c4', {'TRMF_CG': 'replicate'}))
     p, m0 = dist_worker._problem('c4')
     for dtype in (np.float32, np.float64):
         name = np.dtype(dtype).name
@@ -79,7 +159,7 @@ def test_two_ranks_one_gpu_config4_shape_replicated_cg():
         with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
             s.run(iters); st = s.stats(iters); s.download()
         for r in (0, 1):
-            W, H, Th, cg = out[r][name]
+            W, H, Th, cg = out[r][name][:4]
             assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val)
             assert cg == [x['cg_iter'] for x in st]
 
@@ -101,8 +181,8 @@ def test_two_ranks_one_gpu_sharded_cg_gram_product(monkeypatch):
         model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
         with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
             s.run(iters); st = s.stats(iters); s.download()
-        W0, H0, T0, cg0 = out[0][name]
-        W1, H1, T1, cg1 = out[1][name]
+        W0, H0, T0, cg0 = out[0][name][:4]
+        W1, H1, T1, cg1 = out[1][name][:4]
         assert np.array_equal(W0, W1) and np.array_equal(H0, H1) and np.array_equal(T0, T1) and cg0 == cg1
         tol = 1e-9 if dtype == np.float64 else 1e-3
         assert relfro(W0, model.W) < tol and relfro(H0, model.H) < tol and relfro(T0, model.lag_val) < 10 * tol
