@@ -281,7 +281,8 @@ def main():
         traffic = None
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')))
-            if tj.get('config') == args.config and world == 1 and tj.get('kernel_source_sha256') == fsolve_source_digest():
+            tj = tj.get(args.config, tj if tj.get('config') == args.config else {})       # one entry per configuration
+            if world == 1 and tj.get('kernel_source_sha256') == fsolve_source_digest():
                 traffic = tj['traffic_bytes']
         except (OSError, ValueError, KeyError):
             pass
@@ -294,8 +295,8 @@ def main():
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
                 args.config, cfg['n'], cfg['T'], cfg.get('density', 1.0), nnz, cfg['k'], len(prob['lag_set']), dtype.name,
                 int(missing), hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
-                'parallelism': 'item rows of the F-solve and timestamp rows of the X-side Gram build sharded x{} with RCCL all-gathers, each replicated instead when its all-gather costs more than it saves (decided once, from the timings of the second iteration); fused CG replicated (long-lag / large-T problems: cached-Gram product sharded, H d all-gathered per step)'.format(world)},
-            'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_grid_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+                'parallelism': 'item rows of the F-solve and timestamp rows of the X-side Gram build sharded x{} with RCCL all-gathers, each replicated instead when its all-gather costs more than it saves (decided once, from the timings of the second iteration); fused CG replicated or sharded over time (tile records + midx halo rows exchanged per launch), whichever the measured iterations 2-4 find faster (long-lag / large-T problems: cached-Gram product sharded, H d all-gathered per step)'.format(world)},
+            'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_mfma_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
                          'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows'},

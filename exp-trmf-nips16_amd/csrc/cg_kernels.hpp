@@ -33,6 +33,7 @@ struct XState {
     // stop (kCgRunning until then), buffer that holds the final r
     double rho_hist[kCgHistCap + 2];
     int stop_it, r_parity;
+    int p2p_error;                // a peer-to-peer exchange of the time-sharded CG timed out (sticky; reported by sync())
 };
 constexpr int kCgRunning = 0x7fffffff;
 
@@ -512,9 +513,18 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
 // stream of the CG, T*k*k values -- is then in flight for the entire launch while the chain runs on
 // registers and LDS underneath it.  Barriers wait on lgkmcnt only, so the loads stay outstanding.
 // dynamic LDS = hv_tile_lds_bytes(TI, midx, KP, nlag, k)
+// Row pitch (in doubles) of the AR residual rows in LDS.  The adjoint phase reads them with one 16/32-byte vector per
+// thread, thread = (timestamp row, column group): with the pitch equal to the bytes a row's threads actually read
+// (k rounded up to the vector) the 64 threads of a wavefront read ONE contiguous 2 KB range -- conflict-free.  (Round 2
+// used the padded rank: at k = 40 that is 384 bytes, rows two apart fall on the same banks, and 37 % of the LDS cycles
+// of the kernel were bank conflicts, profiles/r02_pmc_hv_tile.txt.)
+__host__ __device__ constexpr int hv_res_pitch(int k) {
+    const int kq = (k + 7) / 8 * 8, vec = (kq <= 40 ? 16 : 8) / (int)sizeof(real);
+    return (k + vec - 1) / vec * vec;
+}
 __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, int nlag = 0, int k = 0) {
     const size_t a = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;
-    const size_t b = ((size_t)(TI + midx) * KP * sizeof(double) + 15) / 16 * 16;
+    const size_t b = ((size_t)(TI + midx) * (k > 0 ? hv_res_pitch(k) : KP) * sizeof(double) + 15) / 16 * 16;
     const size_t c = ((size_t)TI * KP * sizeof(real) + 15) / 16 * 16;                                  // own-row r (fused CG)
     return a + b + c + (size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)nlag * sizeof(int);  // + lambdaAR*Theta, Theta, lag_set
 }
@@ -662,6 +672,56 @@ __device__ __forceinline__ int xcd_contiguous_tile(int b, int n) {
     return x * base + min(x, extra) + i;
 }
 
+// ---- peer-to-peer form of the exchange (TRMF_CG=p2p) ---------------------------------------------------------------------
+// The all-gather of a message costs a collective launch (tens of microseconds) per CG step -- more than the step itself
+// at config 4.  On a node whose GPUs map each other's memory the ranks write their part of a message straight into the
+// peers' copies instead: every rank keeps its message buffers and a flag word per (message, source rank) in ONE arena
+// (uncached device memory, exported with hipIpcGetMemHandle and opened by the peers); a launch stores its tile records
+// into the copy of EVERY rank and its first / last midx rows into the copy of the neighbour that stages them; the small
+// kernel that follows on the stream (all stores of the launch are complete and released by then) raises this rank's flag
+// in every peer's arena to the message's epoch, waits until every peer's flag in the OWN arena has reached it, and
+// unpacks the halo rows.  Epochs only grow; a message buffer is reused two launches later, which a peer cannot reach
+// before it has consumed the previous content (it needs this rank's NEXT message to get there).  Every wait is bounded:
+// a timeout sets XState::p2p_error (the solve is then reported as failed) instead of hanging the GPU.
+constexpr int kMaxPeers = 8;
+struct PeerTable {                              // lives in device memory (indexed by rank at run time)
+    double *msg[3][kMaxPeers];                  // message m in the arena of rank r (own rank: the local copy)
+    unsigned long long *flags[3][kMaxPeers];    // message m's flag words (one 64-byte line per source rank) in the arena of rank r
+};
+constexpr int kFlagStride = 8;                  // 64 bytes between the flags of different source ranks
+constexpr long long kP2pTimeoutTicks = 300000000;   // 3 s of the 100 MHz wall clock
+__global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restrict__ pt, int mi, unsigned long long epoch, XState *__restrict__ st, int it,
+                                                        TileShard sh, int edgeN, int KP, int nvec,
+                                                        real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
+    if (it >= 0 && st->stop_it < it) return;    // launch `it` did nothing (the CG had stopped): no message, on any rank
+    __shared__ int failed;
+    const int tid = threadIdx.x;
+    if (tid == 0) failed = st->p2p_error;
+    __syncthreads();
+    if (tid < sh.world && tid != sh.rank && !failed) {
+        __hip_atomic_store(pt->flags[mi][tid] + (size_t)sh.rank * kFlagStride, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long *mine = pt->flags[mi][sh.rank] + (size_t)tid * kFlagStride;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            if (wall_clock64() - t0 > kP2pTimeoutTicks) { failed = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    if (failed) { if (tid == 0) st->p2p_error = 1; return; }
+    const double *msg = pt->msg[mi][sh.rank];
+    real *dst[kEdgeVecs] = {v0, v1, v2};
+    for (int side = 0; side < 2; side++) {
+        const int nb = side == 0 ? sh.rank - 1 : sh.rank + 1;
+        if (nb < 0 || nb >= sh.world || edgeN == 0) continue;
+        const real *src = reinterpret_cast<const real *>(msg + (size_t)nb * sh.slot_dbl + sh.edge_off_dbl) +
+                          (size_t)(side == 0 ? 1 : 0) * kEdgeVecs * edgeN;
+        const size_t row0 = side == 0 ? (size_t)sh.row_b * KP - edgeN : (size_t)sh.row_e * KP;
+        for (int v = 0; v < nvec; v++)
+            for (int e = tid; e < edgeN; e += 256) dst[v][row0 + e] = __builtin_nontemporal_load(src + (size_t)v * edgeN + e);
+    }
+}
+
 template <int MODE, int KQ, bool SHARD>
 __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,
@@ -669,7 +729,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                                                          const real *__restrict__ theta,
                                                          const real *__restrict__ G,
                                                          const double *__restrict__ rec_in, double *__restrict__ rec_out,
-                                                         int TI) {
+                                                         const PeerTable *__restrict__ pt, int mi, int TI) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
     constexpr bool GRAD = MODE == HV_GRAD;
@@ -688,7 +748,8 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     const int np_in = sh.nbt;                                // records of the previous launch: every tile of the problem
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
-    real *rn = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * KP * sizeof(double) + 15) / 16 * 16));
+    const int RPITCH = hv_res_pitch(k);
+    real *rn = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * RPITCH * sizeof(double) + 15) / 16 * 16));
     double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rn) + (((size_t)TI * KP * sizeof(real) + 15) / 16 * 16));
     real *thp = reinterpret_cast<real *>(thd + (size_t)nlag * KP);
     int *lags = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
@@ -854,11 +915,24 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     // time-sharded CG: does this tile hold any of the rank's first / last midx rows (which the neighbours stage as halo)?
     const int edgeN = Hh * KP;
     const bool edge_tile = SHARD && edgeN > 0 && (i0 < sh.row_b + Hh || i1 > sh.row_e - Hh);
-    real *edges = SHARD ? edge_base(rec_out, sh, sh.rank) : nullptr;
+    // the first rows go to the copy of the rank that stages them as its upper halo (rank - 1), the last rows to rank + 1's;
+    // without peer-to-peer access both land in the local message, which the all-gather then distributes
+    const bool p2p = SHARD && pt != nullptr;
+    real *edges_lo = SHARD ? edge_base(p2p && sh.rank > 0 ? pt->msg[mi][sh.rank - 1] : rec_out, sh, sh.rank) : nullptr;
+    real *edges_hi = SHARD ? edge_base(p2p && sh.rank + 1 < sh.world ? pt->msg[mi][sh.rank + 1] : rec_out, sh, sh.rank) : nullptr;
     auto edge_put = [&](int vec, int ge /* element of the T x KP vector, an own row of this tile */, real x) {
         const uint32_t lo = (uint32_t)(ge - sh.row_b * KP), hi = (uint32_t)(ge - (sh.row_e - Hh) * KP);
-        if (lo < (uint32_t)edgeN) edges[(size_t)vec * edgeN + lo] = x;
-        if (hi < (uint32_t)edgeN) edges[(size_t)(kEdgeVecs + vec) * edgeN + hi] = x;
+        if (lo < (uint32_t)edgeN) edges_lo[(size_t)vec * edgeN + lo] = x;
+        if (hi < (uint32_t)edgeN) edges_hi[(size_t)(kEdgeVecs + vec) * edgeN + hi] = x;
+    };
+    // a tile's record: into the local message, and with peer-to-peer access into the copy of every other rank
+    auto put_record = [&](int first, double a0, double a1, double a2, double a3, bool four) {
+        const size_t ri = rec_index<SHARD>(sh, tile) + first;
+        for (int r = 0; r < (p2p ? sh.world : 1); r++) {
+            double *dst = (p2p ? pt->msg[mi][r] : rec_out) + ri;
+            dst[0] = a0; dst[1] = a1; dst[2] = a2;
+            if (four) dst[3] = a3;
+        }
     };
     if (CG && stopped) {
         // The CLOSING launch (the stop test fired at the top of iteration `it`, or `it` is the iteration cap): s and r of the
@@ -901,10 +975,8 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                     MODE == HV_CG_FIRST ? x : buffer_load_real(g_own, ob), buffer_load_real(w_own, ob));
         }
         block_allsum3(gs, srr, ss, smem);
-        if (tid == 0) {
-            double *rec = rec_out + rec_index<SHARD>(sh, tile);
-            rec[4] = gs; rec[5] = srr; rec[6] = ss;
-        }
+        if (tid == 0) put_record(4, gs, srr, ss, 0, false);
+        if (p2p) __threadfence_system();
         return;
     }
 
@@ -996,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                     const double rv2 = on[u] ? res[u][c] : 0.0;           // rows outside [midx,T): exact zeros
                     if (it < items && tl < k) {
                         if (rr < TI) ar2 += rv2 * rv2;
-                        rs[rr * KP + tl] = rv2;
+                        rs[rr * RPITCH + tl] = rv2;
                     }
                 }
             }
@@ -1034,13 +1106,13 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             // residual rows outside [midx, T) were stored as exact zeros by phase 2, so neither the own-row
             // term nor the lagged terms need a range test; lambdaAR*Theta comes pre-multiplied from LDS
             {
-                const VecOf<double, VEC> r0 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + rr * KP + t0);
+                const VecOf<double, VEC> r0 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + rr * RPITCH + t0);
 #pragma unroll
                 for (int c = 0; c < VEC; c++) od[c] += p.lambdaAR * r0.v[c];
             }
 #pragma unroll 4
             for (int l = 0; l < nlag; l++) {                // VEC neighbouring logical columns: aligned vector reads
-                const VecOf<double, VEC> r4 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + (rr + lags[l]) * KP + t0);
+                const VecOf<double, VEC> r4 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + (rr + lags[l]) * RPITCH + t0);
                 const VecOf<double, VEC> t4 = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
 #pragma unroll
                 for (int c = 0; c < VEC; c++) od[c] -= r4.v[c] * t4.v[c];
@@ -1098,18 +1170,16 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             }
         }
     }
-    double *rec = rec_out + rec_index<SHARD>(sh, tile);
     if (CG) {
         block_allsum3(dot, rhd, hh, smem);
-        if (threadIdx.x == 0) { rec[0] = dot; rec[1] = rhd; rec[2] = hh; }
+        if (threadIdx.x == 0) put_record(0, dot, rhd, hh, 0, false);
+        if (p2p) __threadfence_system();
         return;
     }
     block_allsum3(ar2, vv, dot, smem);
     if (GRAD) lq = block_allsum(lq, smem);
-    if (threadIdx.x == 0) {
-        rec[0] = ar2; rec[1] = vv; rec[2] = dot;             // gradient launch: <g,g>; plain launch: <v,Hv>
-        if (GRAD) rec[3] = lq;
-    }
+    if (threadIdx.x == 0) put_record(0, ar2, vv, dot, lq, GRAD);     // [2]: <g,g> of the gradient launch, <v,Hv> of the plain one
+    if (p2p) __threadfence_system();
 }
 
 // ---- CG initialisation: f, |g|, tolerances; s = 0, r = -g, d = r  (rf_tron.h:154-169, 424-439) ----

@@ -590,7 +590,24 @@ __device__ __forceinline__ double recip_pivot(double d) {
 }
 __host__ __device__ constexpr int upper_tile_index(int ti, int tj, int NT) { return ti * NT - ti * (ti - 1) / 2 + (tj - ti); }
 
-template <int NT, int KMAX>
+// acc += sum_p (lane BC of the caller's 16-lane row: S.v[p]) * R.v[p] -- four v_fmac_f64 with a DPP row broadcast on the first
+// factor.  Inline assembly: the compiler keeps the broadcast as a separate v_mov_b64_dpp (one more fp64-rate instruction
+// per product).  The leading s_nop covers the two wait states a DPP read needs after a VALU write of its source.
+template <int BC>
+__device__ __forceinline__ void fmac4_row_bcast(double &acc, const Quad<double> &S, const Quad<double> &R) {
+    asm("s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %1, %5 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %2, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %3, %7 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+        "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(acc)
+        : "v"(S.v[0]), "v"(S.v[1]), "v"(S.v[2]), "v"(S.v[3]), "v"(R.v[0]), "v"(R.v[1]), "v"(R.v[2]), "v"(R.v[3]), "n"(BC));
+}
+#ifndef TRMF_TRAIL_MFMA
+#define TRMF_TRAIL_MFMA 1      // measured at config 5: 12.6-12.8 ms with the MFMA trailing update, 13.0 ms with the DPP-fused FMAs (7b)
+#endif
+
+template <int NT, int KMAX, bool TRAIL_MFMA = (TRMF_TRAIL_MFMA != 0)>
 __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
                                                                           const uint32_t *__restrict__ idx,
                                                                           const real *__restrict__ val,
@@ -600,7 +617,7 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
                                                                           uint32_t zero_row) {
     static_assert(sizeof(real) == 8, "the in-accumulator F-solve is the fp64 path");
     constexpr int KP = kTile * NT, NPAN = KMAX / 4;
-    constexpr int CP = 10;                                // doubles per column record: R'0 S0 R'1 S1 R'2 S2 R'3 S3 + 2 pad
+    constexpr int CP = 10;                                // doubles per column record: R'0 R'1 R'2 R'3 | S0 S1 S2 S3 | 2 pad (80-byte pitch)
     constexpr int FIN = (KP + 1) * CP;                    // after the records of columns 0..KP-1 and of the rhs: (z'_q, 1/d_q) x 4
     constexpr int RP = KP + 2;                            // row pitch of the back substitution's column buffer
     constexpr int SCR = (FIN + 8 > kTile * RP) ? FIN + 8 : kTile * RP;
@@ -677,8 +694,8 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
         const real R3 = fma(-l32, R2, fma(-l31, R1, fma(-l30, R0, rin.v[3])));
         const real S0 = -(R0 * i0), S1 = -(R1 * i1), S2 = -(R2 * i2), S3 = -(R3 * i3);
         if (has_col) {
-            *reinterpret_cast<Quad<real> *>(rec) = Quad<real>{{R0, S0, R1, S1}};
-            *reinterpret_cast<Quad<real> *>(rec + 4) = Quad<real>{{R2, S2, R3, S3}};
+            *reinterpret_cast<Quad<real> *>(rec) = Quad<real>{{R0, R1, R2, R3}};
+            *reinterpret_cast<Quad<real> *>(rec + 4) = Quad<real>{{S0, S1, S2, S3}};
         }
         if (lane == j0) {                                // eliminated rhs entries z'_q and the pivots' reciprocals
             *reinterpret_cast<Quad<real> *>(ps + FIN) = Quad<real>{{R0, i0, R1, i1}};
@@ -696,25 +713,55 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
             y = in_panel ? mine.v[0] : (lane > j0 + 3 ? upd : y);
             dinv = in_panel ? mine.v[1] : dinv;
         }
-        // (6) lane group g reads its row back: final pivot row (B operand, kept in the accumulators) and scaled copy (A operand)
-        real aop[NT];
+        // (6) lane group g reads its row back (the final pivot row stays in the accumulators for the back substitution)
 #pragma unroll
-        for (int tj = tp; tj < NT; tj++) {
-            const pair_t rs = *reinterpret_cast<const pair_t *>(ps + (kTile * tj + c) * CP + 2 * g);
-            st.acc[upper_tile_index(tp, tj, NT)][r0] = rs.v[0];
-            aop[tj] = rs.v[1];
+        for (int tj = tp; tj < NT; tj++) st.acc[upper_tile_index(tp, tj, NT)][r0] = ps[(kTile * tj + c) * CP + g];
+        if constexpr (TRAIL_MFMA) {
+            // (7a) trailing update on the matrix pipe: the scaled copy of the lane group's row is the A operand, the pivot
+            //      row itself the B operand of ONE v_mfma_f64_16x16x4 per trailing tile
+            real aop[NT];
+#pragma unroll
+            for (int tj = tp; tj < NT; tj++) aop[tj] = ps[(kTile * tj + c) * CP + 4 + g];
+            if (c <= 4 * r0 + 3) aop[tp] = 0;            // rows at and above the panel are final: the update leaves them alone
+            wave_lds_sync();
+#pragma unroll
+            for (int ti = tp; ti < NT; ti++)
+#pragma unroll
+                for (int tj = ti; tj < NT; tj++) {
+                    acc_t &C = st.acc[upper_tile_index(ti, tj, NT)];
+                    C = Mfma16<real>::mma(aop[ti], st.acc[upper_tile_index(tp, tj, NT)][r0], C);
+                }
+        } else {
+            // (7b) trailing update on the vector ALUs.  v_mfma_f64_16x16x4 issues in ~100 cycles per SIMD on gfx950
+            //      (scripts/ubench/f64_pipe.hip: 20 flop/clk against 26-32 of v_fma_f64), and a whole-tile update cannot skip
+            //      the rows of a tile row that are already final; here register r of tile (ti, tj) takes
+            //          A[16 ti + g + 4 r][16 tj + c] += sum_p S_p[16 ti + g + 4 r] R'_p[16 tj + c]
+            //      as four v_fmac_f64 whose row operand is a DPP row broadcast (row_newbcast is the one DPP mode fp64 has): the
+            //      lane reads the scaled rows of the column its 16-lane row is ROTATED to, column 16 ti + (c + g) mod 16, so
+            //      that lane 4 r of every row holds S_p[16 ti + g + 4 r].  Rows at and above the panel (registers r <= r0 of
+            //      tile row tp) are skipped: 880 FMAs per rank-64 system, no masks, no MFMA hazard nops.
+            Quad<real> Rq[NT];
+#pragma unroll
+            for (int tj = tp; tj < NT; tj++) Rq[tj] = *reinterpret_cast<const Quad<real> *>(ps + (kTile * tj + c) * CP);
+            static_for<NT>([&](auto Ti) {
+                constexpr int ti = decltype(Ti)::value;
+                if constexpr (ti >= tp) {
+                    const Quad<real> Sq = *reinterpret_cast<const Quad<real> *>(ps + (kTile * ti + ((c + g) & 15)) * CP + 4);
+                    static_for<4>([&](auto Rr) {
+                        constexpr int r = decltype(Rr)::value;
+                        if constexpr (ti > tp || r > r0) {
+#pragma unroll
+                            for (int tj = ti; tj < NT; tj++) {
+                                real a = st.acc[upper_tile_index(ti, tj, NT)][r];
+                                fmac4_row_bcast<4 * r>(a, Sq, Rq[tj]);
+                                st.acc[upper_tile_index(ti, tj, NT)][r] = a;
+                            }
+                        }
+                    });
+                }
+            });
+            wave_lds_sync();
         }
-        if (c <= 4 * r0 + 3) aop[tp] = 0;                // rows at and above the panel are final: the update leaves them alone
-        wave_lds_sync();
-        // (7) trailing update on the matrix pipe
-#pragma unroll
-        for (int ti = tp; ti < NT; ti++)
-#pragma unroll
-            for (int tj = ti; tj < NT; tj++) {
-                constexpr int dummy = 0; (void)dummy;
-                acc_t &C = st.acc[upper_tile_index(ti, tj, NT)];
-                C = Mfma16<real>::mma(aop[ti], st.acc[upper_tile_index(tp, tj, NT)][r0], C);
-            }
     });
 
     // ---- back substitution (D L^T) x = z', column oriented, lane = row ----

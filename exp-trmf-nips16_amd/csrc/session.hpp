@@ -121,8 +121,19 @@ struct TrmfSessionImpl {
     // fused path: per-tile records of each launch (cg_kernels.hpp "per-tile partial records") in three message buffers:
     // CG launches of even / odd iteration, gradient + plain launch.  tsh: the one-rank view (one slot, every tile);
     // tsh_rank: this rank's block of tiles when the CG is sharded over time (ts_possible).
-    DevBuf<double> xmsg[3];
+    DevBuf<double> xmsg_own[3];               // backing store of the messages unless they live in the peer-to-peer arena
+    double *xm[3] = {nullptr, nullptr, nullptr};
     TileShard tsh{}, tsh_rank{};
+    // peer-to-peer exchange (TRMF_CG=p2p; cg_kernels.hpp "peer-to-peer form of the exchange"): messages + flag words of
+    // this rank in one IPC-exported arena, the peers' arenas opened, the pointer table in device memory
+    struct P2p {
+        bool on = false, uncached = false;
+        void *arena = nullptr;
+        size_t bytes = 0;
+        std::vector<void *> peer;             // opened arenas of the other ranks (own slot: nullptr)
+        unsigned long long epoch[3] = {0, 0, 0};
+    } p2p;
+    DevBuf<PeerTable> peer_table;
     std::vector<uint64_t> tbounds;            // tile-aligned timestamp partition of the time-sharded CG
     bool ts_possible = false;
     enum { kTsOff = 0, kTsOn = 1, kTsMeasure = 2 };
@@ -140,7 +151,62 @@ struct TrmfSessionImpl {
             for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
         }
         for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2, ts0, ts1}) if (ev) (void)hipEventDestroy(ev);
+        release_p2p();
         if (stream) (void)hipStreamDestroy(stream);
+    }
+    void release_p2p() {
+        for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
+        p2p.peer.clear();
+        if (p2p.arena) (void)hipFree(p2p.arena);
+        p2p.arena = nullptr; p2p.on = false;
+    }
+    // One arena per rank: [message 0 | message 1 | message 2 | flag words: 3 messages x world source ranks x 64 bytes].
+    // Collective: every rank allocates, exports its handle, gathers the handles (through the communicator) and opens the
+    // other ranks' arenas.  Explicitly requested (TRMF_CG=p2p), so every failure is reported instead of falling back.
+    int setup_p2p(size_t msg_doubles) {
+        const int W_ = comm->world;
+        if (W_ > kMaxPeers) { set_error("TRMF_CG=p2p supports at most 8 ranks"); return kFail; }
+        const size_t msg_bytes = (msg_doubles * sizeof(double) + 255) / 256 * 256, flag_bytes = (size_t)3 * W_ * kFlagStride * sizeof(unsigned long long);
+        p2p.bytes = 3 * msg_bytes + flag_bytes;
+        p2p.uncached = hipExtMallocWithFlags(&p2p.arena, p2p.bytes, hipDeviceMallocUncached) == hipSuccess;
+        if (!p2p.uncached) {
+            (void)hipGetLastError();
+            TRMF_HIP_CHECK(hipMalloc(&p2p.arena, p2p.bytes));
+        }
+        TRMF_HIP_CHECK(hipMemsetAsync(p2p.arena, 0, p2p.bytes, stream));
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        hipIpcMemHandle_t mine;
+        TRMF_HIP_CHECK(hipIpcGetMemHandle(&mine, p2p.arena));
+        static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle slot");
+        DevBuf<unsigned char> slots;
+        if (slots.alloc((size_t)64 * W_)) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(slots.p + (size_t)64 * comm->rank, &mine, sizeof mine, hipMemcpyHostToDevice, stream));
+        if (comm->allgather_slots(slots.p, 64, stream)) return kFail;
+        std::vector<unsigned char> all((size_t)64 * W_);
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        TRMF_HIP_CHECK(hipMemcpy(all.data(), slots.p, all.size(), hipMemcpyDeviceToHost));
+        p2p.peer.assign(W_, nullptr);
+        PeerTable tab{};
+        for (int r = 0; r < W_; r++) {
+            unsigned char *base = (unsigned char *)p2p.arena;
+            if (r != comm->rank) {
+                hipIpcMemHandle_t h;
+                std::memcpy(&h, all.data() + (size_t)64 * r, sizeof h);
+                TRMF_HIP_CHECK(hipIpcOpenMemHandle(&p2p.peer[r], h, hipIpcMemLazyEnablePeerAccess));
+                base = (unsigned char *)p2p.peer[r];
+            }
+            for (int m = 0; m < 3; m++) {
+                tab.msg[m][r] = reinterpret_cast<double *>(base + m * msg_bytes);
+                tab.flags[m][r] = reinterpret_cast<unsigned long long *>(base + 3 * msg_bytes) + (size_t)m * W_ * kFlagStride;
+            }
+        }
+        if (peer_table.upload(&tab, 1)) return kFail;
+        for (int m = 0; m < 3; m++) { xm[m] = tab.msg[m][comm->rank]; p2p.epoch[m] = 0; }
+        p2p.on = true;
+        // nobody starts writing into a peer before every rank has opened every arena
+        if (comm->allgather_slots(slots.p, 64, stream)) return kFail;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        return 0;
     }
 
     double *P(int slot) { return partials.p + (size_t)slot * xp.pstride; }
@@ -421,11 +487,15 @@ struct TrmfSessionImpl {
                 doubles = std::max(doubles, (size_t)W_ * tsh_rank.slot_dbl);
             }
         }
-        for (auto &m : xmsg) if (m.alloc(doubles)) return kFail;
-        if (const char *e = getenv("TRMF_CG")) {
-            if (e[0] == 't') ts_mode = kTsOn;                  // timeshard
-            else if (e[0] == 'r') ts_mode = kTsOff;            // replicate
+        release_p2p();
+        const char *e = getenv("TRMF_CG");
+        if (e && e[0] == 't') ts_mode = kTsOn;                 // timeshard: exchange through the communicator
+        else if (e && e[0] == 'r') ts_mode = kTsOff;           // replicate
+        else if (e && e[0] == 'p') {                           // p2p: time-sharded, peer-to-peer exchange
+            ts_mode = kTsOn;
+            if (ts_possible) return setup_p2p(doubles);
         }
+        for (int m = 0; m < 3; m++) { if (xmsg_own[m].alloc(doubles)) return kFail; xm[m] = xmsg_own[m].p; }
         return 0;
     }
 
@@ -874,9 +944,11 @@ struct TrmfSessionImpl {
     template <int MODE, bool SHARD> void launch_hv_tile_as(const HvVecs &a, int it, int last, const double *rec_in, double *rec_out) {
         const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
         const TileShard &sh = SHARD ? tsh_rank : tsh;
+        const PeerTable *pt = (SHARD && p2p.on) ? peer_table.p : nullptr;
+        const int mi = rec_out == xm[0] ? 0 : rec_out == xm[1] ? 1 : 2;
 #define TRMF_LAUNCH_HV_KQ(KQ)                                                                                        \
         hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ, SHARD>), dim3(sh.ntiles), dim3(256), lds, stream, xp, xstate.p, a, sh, it, last,  \
-                           lag_set.p, theta.p, Gmat(), rec_in, rec_out, tile_TI)
+                           lag_set.p, theta.p, Gmat(), rec_in, rec_out, pt, mi, tile_TI)
         switch (hv_kq(k) / 8) {
             case 1: TRMF_LAUNCH_HV_KQ(8); break;
             case 2: TRMF_LAUNCH_HV_KQ(16); break;
@@ -895,8 +967,19 @@ struct TrmfSessionImpl {
     }
     // time-sharded CG: exchange the slots of a message (tile records + edge rows of every rank), then copy the
     // neighbours' edge rows of up to three vectors to their natural rows of the local vectors
-    int exchange_message(DevBuf<double> &m) {
-        return comm->allgather_slots(m.p, (size_t)tsh_rank.slot_dbl * sizeof(double), stream);
+    // one exchange of message `mi` after a launch (`it`: the CG launch index, -1 for the gradient / plain launch) and the
+    // unpacking of the neighbours' edge rows of nvec vectors: through the communicator (in-place all-gather of the slots +
+    // halo_unpack_kernel) or peer to peer (the launch wrote into the peers' arenas; xchg_sync_kernel raises / awaits the flags)
+    int exchange(int mi, int it, int nvec, real *v0, real *v1, real *v2) {
+        const int edgeN = midx * KP;
+        if (p2p.on) {
+            hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, mi, ++p2p.epoch[mi], xstate.p, it, tsh_rank,
+                               edgeN, KP, nvec, v0, v1, v2);
+            return 0;
+        }
+        if (comm->allgather_slots(xm[mi], (size_t)tsh_rank.slot_dbl * sizeof(double), stream)) return kFail;
+        if (nvec > 0) unpack_halo(xm[mi], xm[mi], 0, nvec, v0, v1, v2);
+        return 0;
     }
     void unpack_halo(const double *m0, const double *m1, int by_parity, int nvec, real *v0, real *v1, real *v2) {
         const int edgeN = midx * KP;
@@ -912,24 +995,27 @@ struct TrmfSessionImpl {
     // from identical records, so they take identical decisions (the collectives match).
     int xsolve_fused(bool shard, int maxcg, XState *log_x, double *log_n) {
         real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
-        double *mg = xmsg[2].p, *mc[2] = {xmsg[0].p, xmsg[1].p};
+        double *mg = xm[2], *mc[2] = {xm[0], xm[1]};
         HvVecs a{};
         a.v = W.p; a.out = g.p; a.Bv = Bv.p;
         launch_hv_tile<HV_GRAD>(shard, a, 0, 0, nullptr, mg);                  // gradient, <g,g>, AR/ridge sums
-        if (shard) { if (exchange_message(xmsg[2])) return kFail; unpack_halo(mg, mg, 0, 1, g.p, nullptr, nullptr); }
+        if (shard && exchange(2, -1, 1, g.p, nullptr, nullptr)) return kFail;
         a = HvVecs{};
         a.v = g.p; a.s = s.p; a.d_out = dbuf[0]; a.r_out = rbuf[0]; a.out = hbuf[0];
         a.g = g.p; a.w = W.p; a.w_new = w_new.p;
         launch_hv_tile<HV_CG_FIRST>(shard, a, 0, 0, mg, mc[0]);                // f, |g|, cgtol; s = 0, r = d = -g; H d
-        if (shard) { if (exchange_message(xmsg[0])) return kFail; unpack_halo(mc[0], mc[0], 0, 3, dbuf[0], rbuf[0], hbuf[0]); }
-        int upto = shard ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
+        if (shard && exchange(0, 0, 3, dbuf[0], rbuf[0], hbuf[0])) return kFail;
+        // host-followed progress only where an exchange costs a collective; peer to peer (and on one rank) the launches of
+        // iterations that will not run are no-ops on the device and everything is enqueued at once
+        const bool follow = shard && !p2p.on;
+        int upto = follow ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
         for (int it = 1; it <= maxcg; it++) {                              // launch `maxcg` only closes the last iteration
             a.v = dbuf[(it - 1) & 1]; a.r_in = rbuf[(it - 1) & 1]; a.hd_in = hbuf[(it - 1) & 1];
             a.d_out = dbuf[it & 1]; a.r_out = rbuf[it & 1]; a.out = hbuf[it & 1];
             launch_hv_tile<HV_CG_STEP>(shard, a, it, it == maxcg ? 1 : 0, mc[(it - 1) & 1], mc[it & 1]);
             if (!shard) continue;
-            if (exchange_message(xmsg[it & 1])) return kFail;
-            unpack_halo(mc[it & 1], mc[it & 1], 0, 3, dbuf[it & 1], rbuf[it & 1], hbuf[it & 1]);
+            if (exchange(it & 1, it, 3, dbuf[it & 1], rbuf[it & 1], hbuf[it & 1])) return kFail;
+            if (!follow) continue;
             if (it == upto && it < maxcg) {                                // has the CG stopped?  (identical on every rank)
                 int stop = kCgRunning;
                 TRMF_HIP_CHECK(hipMemcpyAsync(&stop, &xstate.p->stop_it, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -942,7 +1028,7 @@ struct TrmfSessionImpl {
         a = HvVecs{};
         a.v = s.p; a.out = hbuf[0];
         launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs>
-        if (shard && exchange_message(xmsg[2])) return kFail;
+        if (shard && exchange(2, -1, 0, nullptr, nullptr, nullptr)) return kFail;
         const TileShard &sh = shard ? tsh_rank : tsh;
         const int nb = (int)std::min<size_t>(kMaxPartials, ((size_t)(sh.row_e - sh.row_b) * KP + 255) / 256);
         hipLaunchKernelGGL(accept_tile_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mc[0], mc[1], mg, sh,
@@ -1201,6 +1287,11 @@ struct TrmfSessionImpl {
 
     int sync() {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        if (p2p.on) {               // a bounded wait of the peer-to-peer exchange ran out: the factors are not to be trusted
+            int bad = 0;
+            TRMF_HIP_CHECK(hipMemcpy(&bad, &xstate.p->p2p_error, sizeof bad, hipMemcpyDeviceToHost));
+            if (bad) { set_error("time-sharded CG: a peer-to-peer exchange timed out (TRMF_CG=p2p)"); return kFail; }
+        }
         return 0;
     }
 

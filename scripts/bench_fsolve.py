@@ -14,8 +14,8 @@ big = 10 ** 6
 with session.Session(p['Y'], m, missing=True, period_W=big, period_Lag=big, **synth.HYPER) as s:
     s.run(12); st = s.stats(10); s.download(); B = s.fsolve_bytes()
 ms = np.array([x['ms_F_kernel'] for x in st])
-print('%s fsolve kernel: avg %.1f us  min %.1f  max %.1f  ->  %.0f GB/s (%.1f%% of 8 TB/s) on B_F=%.3f GB' % (
-    cfgname, 1e3 * ms.mean(), 1e3 * ms.min(), 1e3 * ms.max(), B / ms.mean() / 1e6, 100 * B / ms.mean() / 1e6 / 8000, B / 1e9))
+print('%s nnz=%d fsolve kernel: avg %.1f us  min %.1f  max %.1f  ->  %.0f GB/s (%.1f%% of 8 TB/s) on B_F=%.3f GB' % (
+    cfgname, p['Y'].nnz, 1e3 * ms.mean(), 1e3 * ms.min(), 1e3 * ms.max(), B / ms.mean() / 1e6, 100 * B / ms.mean() / 1e6 / 8000, B / 1e9))
 Yc = p['Y'].tocsc(); k = cfg['k']; worst = 0
 for i in np.random.RandomState(0).choice(cfg['n'], 300, replace=False):
     tt = Yc.indices[Yc.indptr[i]:Yc.indptr[i + 1]]

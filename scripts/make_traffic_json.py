@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""profiles/fsolve_traffic.json from a PMC summary written by scripts/pmc_fsolve.sh.
+"""profiles/fsolve_traffic.json (one entry per configuration) from a PMC summary written by scripts/pmc_fsolve.sh.
 
-    python scripts/make_traffic_json.py profiles/r02_pmc_fsolve.txt
+    python scripts/make_traffic_json.py profiles/r03_pmc_fsolve.txt [c3|c5]
 
 HBM bytes per F-solve launch = 2 x FETCH_SIZE + WRITE_SIZE (both reported in KB): FETCH_SIZE under-counts wide
 coalesced streaming reads by exactly 2x on gfx950 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section);
@@ -29,16 +29,30 @@ try:
     commit = subprocess.run(['git', '-C', ROOT, 'rev-parse', '--short', 'HEAD'], capture_output=True, text=True).stdout.strip()
 except OSError:
     commit = ''
-nnz, n, T, k, s = 9950287, 100000, 10000, 40, 4
+config = sys.argv[2] if len(sys.argv) > 2 else 'c3'
+nnz, n, T, k, s, kernel = {'c3': (9950287, 100000, 10000, 40, 4, 'fsolve_quad_kernel<3,40>'),
+                           'c5': (49975021, 1000000, 50000, 64, 8, 'fsolve_mfma_kernel<4,64>')}[config]
+for line in open(src):                       # the summary records the entry count of the run it was taken on
+    m = re.search(r'nnz[= ](\d+)', line)
+    if m:
+        nnz = int(m.group(1))
 out = {
     'note': __doc__.split('\n\n')[2].replace('\n', ' '),
     'source': os.path.relpath(src, ROOT), 'source_commit': commit, 'kernel_source_sha256': fsolve_source_digest(),
-    'config': 'c3', 'kernel': 'fsolve_quad_kernel<3,40>',
+    'config': config, 'kernel': kernel,
     'fetch_size_kb': fetch_kb, 'write_size_kb': write_kb,
     'traffic_bytes': int(round((2 * fetch_kb + write_kb) * 1024)),
     'tcc_hit_rate': vals['TCC_HIT'] / (vals['TCC_HIT'] + vals['TCC_MISS']) if 'TCC_HIT' in vals else None,
     'algorithmic_bytes': nnz * (4 + s + k * s) + (n + 1) * 8 + n * k * s,
     'compulsory_bytes': nnz * (4 + s) + (n + 1) * 8 + T * k * s + n * k * s,
 }
-json.dump(out, open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json'), 'w'), indent=2)
+path = os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')
+try:
+    table = json.load(open(path))
+    if 'traffic_bytes' in table:             # round-2 format: a single config-3 entry
+        table = {table.get('config', 'c3'): table}
+except (OSError, ValueError):
+    table = {}
+table[config] = out
+json.dump(table, open(path, 'w'), indent=2)
 print(json.dumps(out, indent=2))

@@ -11,15 +11,21 @@ sys.path.insert(0, ROOT)
 
 def test_traffic_profile_belongs_to_the_current_kernel_sources():
     import bench
-    tj = json.load(open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')))
-    assert tj['kernel_source_sha256'] == bench.fsolve_source_digest(), \
-        'profiles/fsolve_traffic.json is stale: re-run scripts/pmc_fsolve.sh on a GPU box and scripts/make_traffic_json.py'
-    # byte model of SURVEY.md 8(d) at config 3
-    nnz, n, T, k, s = 9950287, 100000, 10000, 40, 4
-    assert tj['algorithmic_bytes'] == nnz * (4 + s + k * s) + (n + 1) * 8 + n * k * s
-    assert tj['compulsory_bytes'] == nnz * (4 + s) + (n + 1) * 8 + T * k * s + n * k * s
-    assert tj['traffic_bytes'] == round((2 * tj['fetch_size_kb'] + tj['write_size_kb']) * 1024)
-    assert os.path.exists(os.path.join(ROOT, tj['source']))
+    table = json.load(open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')))
+    assert 'c3' in table, 'the headline configuration must carry a PMC traffic figure'
+    shapes = {'c3': (100000, 10000, 40, 4), 'c5': (1000000, 50000, 64, 8)}      # n, T, k, sizeof(element)
+    for config, tj in table.items():
+        assert tj['config'] == config
+        assert tj['kernel_source_sha256'] == bench.fsolve_source_digest(), \
+            'profiles/fsolve_traffic.json[%s] is stale: re-run scripts/pmc_fsolve.sh on a GPU box and scripts/make_traffic_json.py' % config
+        # byte model of SURVEY.md 8(d)
+        n, T, k, s = shapes[config]
+        nnz = (tj['algorithmic_bytes'] - (n + 1) * 8 - n * k * s) // (4 + s + k * s)
+        assert tj['algorithmic_bytes'] == nnz * (4 + s + k * s) + (n + 1) * 8 + n * k * s
+        assert tj['compulsory_bytes'] == nnz * (4 + s) + (n + 1) * 8 + T * k * s + n * k * s
+        assert abs(nnz - {'c3': 9950287, 'c5': 49975000}[config]) < 100000       # the synthetic generator's entry count
+        assert tj['traffic_bytes'] == round((2 * tj['fetch_size_kb'] + tj['write_size_kb']) * 1024)
+        assert os.path.exists(os.path.join(ROOT, tj['source']))
 
 
 def test_cpu_baseline_worker_protocol():

@@ -76,13 +76,17 @@ def _single_process(p, m0, dtype, iters):
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,shape,mode', [(2, 'small', 'timeshard'), (2, 'odd', 'timeshard'), (2, 'c4', 'timeshard'),
                                               (4, 'c4', 'timeshard'), (8, 'c4', 'timeshard'), (3, 'c4', 'measure'),
-                                              (4, 'c4', 'replicate')])
+                                              (4, 'c4', 'replicate'), (2, 'small', 'p2p'), (2, 'c4', 'p2p'), (4, 'c4', 'p2p'),
+                                              (8, 'c4', 'p2p')])
 def test_time_sharded_cg_matches_single_process(world, shape, mode):
     """The CG sharded over TIME: every rank runs the tiles of its own block of timestamps, the tile
     records (three scalars per CG step) and midx halo rows per neighbour are exchanged after every launch.  Same
     records summed in the same order => bit-identical to the single-process run, in both precisions, for 2 / 3 / 4 / 8
     ranks (uneven last block at 'odd'), forced (TRMF_CG=timeshard), forced off, and under the measure-once rule (which
-    runs iterations 1-2 replicated and 3-4 time-sharded, then decides: 5 iterations cover the switch both ways)."""
+    runs iterations 1-2 replicated and 3-4 time-sharded, then decides: 5 iterations cover the switch both ways).
+    'p2p': the peer-to-peer form of the exchange -- every rank's kernels write their tile records and edge rows straight
+    into the other ranks' IPC-mapped message buffers and synchronise through flag words (bounded waits); here the "peers"
+    are processes sharing the one GPU, the code path (IPC handles, remote stores, system-scope flags) is the multi-GPU one."""
     import dist_worker
     iters = 5 if mode == 'measure' else 3
     env = {} if mode == 'measure' else {'TRMF_CG': mode}
@@ -128,7 +132,7 @@ def test_config4_full_size_sharded_paths_on_one_gpu(world):
     iters = 2
     ref_dig, ref_cg = _c3_single_process_digests(iters)
     report = {}
-    for mode in ('replicate', 'timeshard'):
+    for mode in ('replicate', 'timeshard', 'p2p'):
         out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c3full', {'TRMF_CG': mode, 'TRMF_FSHARD': 'shard', 'TRMF_GRAMX': 'shard'},
                           ('float32',)))
         for r in range(world):

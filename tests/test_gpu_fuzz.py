@@ -12,6 +12,12 @@ from helpers import TOL, make_model, relfro
 
 pytestmark = pytest.mark.gpu
 
+# Round 2 relaxed the fp32 factor gate 5x (5e-3) for every case.  Measured in round 3 (profiles/r03_fuzz_margins.txt: the
+# margin of every case to the DIRECT gate of SURVEY.md 8(d), printed with -s): the worst fp32 case sits at 0.165 of the
+# direct gate, all others below 0.02 -- no case needs a relaxation, so none is granted.
+RELAXED_F32_SEEDS = set()
+RELAXED_F32_PERIOD_SEEDS = set()
+
 
 def _case(seed):
     rng = np.random.RandomState(1000 + seed)
@@ -51,10 +57,12 @@ def test_random_shapes_vs_restatement(seed):
     model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
     trmf.train(Y, model, max_iter=2, missing=missing, **hyper)
     tol = TOL[np.dtype(dtype).name]
-    fac = tol['factor'] if dtype == np.float64 else 5 * tol['factor']       # tiny, ill-conditioned fp32 systems: 5e-3
+    fac = 5 * tol['factor'] if (dtype == np.float32 and seed in RELAXED_F32_SEEDS) else tol['factor']
     what = 'seed %d: %s k=%d lags=%s T=%d n=%d missing=%s %s' % (seed, np.dtype(dtype).name, k, lags.tolist(), Y.shape[0], Y.shape[1],
                                                               missing, 'sparse' if smat.issparse(Y) else 'dense')
-    print(what, '| relfro W %.1e H %.1e Th %.1e' % (relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th)))
+    worst = max(relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th) / 10)
+    print(what, '| relfro W %.1e H %.1e Th %.1e | FUZZ-MARGIN seed %d %s: %.3f of the direct gate' % (
+        relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th), seed, np.dtype(dtype).name, worst / tol['factor']))
     assert np.all(np.isfinite(model.W)) and np.all(np.isfinite(model.H)) and np.all(np.isfinite(model.lag_val)), what
     assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac, what
 
@@ -74,7 +82,9 @@ def test_random_period_gating_vs_restatement(seed):
     O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=5, periods=periods, threads=2)
     model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
     trmf.train(Y, model, max_iter=5, period_W=periods[0], period_H=periods[1], period_Lag=periods[2], missing=True, **hyper)
-    fac = TOL[np.dtype(dtype).name]['factor'] * (1 if dtype == np.float64 else 5)
+    fac = TOL[np.dtype(dtype).name]['factor'] * (5 if (dtype == np.float32 and seed in RELAXED_F32_PERIOD_SEEDS) else 1)
+    print('FUZZ-MARGIN period seed %d %s periods %s: %.3f of the direct gate' % (seed, np.dtype(dtype).name, periods, max(
+        relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th) / 10) / TOL[np.dtype(dtype).name]['factor']))
     assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac, periods
     if periods[0] > 5: assert np.array_equal(model.W, m0.W)
     if periods[1] > 5: assert np.array_equal(model.H, m0.H)
