@@ -518,10 +518,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
 // (k rounded up to the vector) the 64 threads of a wavefront read ONE contiguous 2 KB range -- conflict-free.  (Round 2
 // used the padded rank: at k = 40 that is 384 bytes, rows two apart fall on the same banks, and 37 % of the LDS cycles
 // of the kernel were bank conflicts, profiles/r02_pmc_hv_tile.txt.)
-__host__ __device__ constexpr int hv_res_pitch(int k) {
-    const int kq = (k + 7) / 8 * 8, vec = (kq <= 40 ? 16 : 8) / (int)sizeof(real);
-    return (k + vec - 1) / vec * vec;
-}
+__host__ __device__ constexpr int hv_res_pitch(int k) { return (k + 7) / 8 * 8; }    // = KQ: a compile-time constant of the kernel
 __host__ __device__ inline size_t hv_tile_lds_bytes(int TI, int midx, int KP, int nlag = 0, int k = 0) {
     const size_t a = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;
     const size_t b = ((size_t)(TI + midx) * (k > 0 ? hv_res_pitch(k) : KP) * sizeof(double) + 15) / 16 * 16;
@@ -601,8 +598,6 @@ struct HvVecs {
     real *r_out;          // CG_*: new residual
     real *out;            // H v / gradient / H d
     const real *Bv;       // GRAD: right-hand sides
-    const real *g, *w;    // CG_*: gradient and current iterate (read by the CLOSING launch only: w_new = w + s, <g,s>)
-    real *w_new;          // CG_*: the candidate iterate (written by the closing launch)
 };
 
 // ---- per-tile partial records and the time-sharded CG ------------------------------------------
@@ -610,11 +605,11 @@ struct HvVecs {
 // every rank derives bit-identical scalars from them):
 //     gradient launch      [0] AR residual^2   [1] <w,w>      [2] <g,g>      [3] w.(Gw) - 2 b.w
 //     CG launch `it`       [0] <d,Hd>          [1] <r,Hd>     [2] <Hd,Hd>
-//     the CLOSING launch   [4] <g,s>           [5] <s,r>      [6] <s,s>      (w_new = w + s is written there too)
-//     plain launch (H s)   [0] AR residual^2   [1] <s,s>      [2] <s,Hs>
+//     cg_close_kernel      [4] <g,s>           [5] <s,r>      [6] <s,s>      (closes the last iteration: s, w_new = w + s)
+//     plain launch (H s)   [0] AR residual^2   [1] <s,s>      [2] <s,Hs>     (same message as cg_close_kernel's)
 // The records of a launch live in a MESSAGE buffer of `world` equal slots; slot r holds the records of rank r's tiles
 // followed by the rank's EDGE rows -- the first and the last midx rows of its timestamp block of up to three vectors
-// (d, r, H d of a CG launch; g of the gradient launch; s of the closing launch).  With one rank there is one slot and
+// (d, r, H d of a CG launch; g of the gradient launch; s of cg_close_kernel).  With one rank there is one slot and
 // no edges.  With several ranks every rank runs the tiles of its own contiguous block of timestamps (the Hessian is
 // block-diagonal per timestamp, trmf.cpp:269-288; the AR stencil reaches midx rows, trmf.cpp:125-149; the CG needs
 // three scalars per step, rf_tron.h:460-501): after each launch the slots are exchanged (one in-place all-gather of
@@ -643,13 +638,10 @@ __device__ __forceinline__ real *edge_base(double *msg, const TileShard &sh, int
     return reinterpret_cast<real *>(msg + (size_t)rank * sh.slot_dbl + sh.edge_off_dbl);
 }
 // The neighbours' edge rows -> their natural rows of the local vectors (rows [row_b - midx, row_b) from the LAST rows of
-// rank - 1, rows [row_e, row_e + midx) from the FIRST rows of rank + 1).  by_parity: the message is msg0 or msg1 by
-// XState::r_parity (the closing launch's message, whose vector 0 is the step s).
-__global__ __launch_bounds__(256) void halo_unpack_kernel(const double *__restrict__ msg0, const double *__restrict__ msg1,
-                                                          const XState *__restrict__ st, int by_parity, TileShard sh,
+// rank - 1, rows [row_e, row_e + midx) from the FIRST rows of rank + 1).
+__global__ __launch_bounds__(256) void halo_unpack_kernel(const double *__restrict__ msg, TileShard sh,
                                                           int edgeN /* midx * KP */, int KP, int nvec,
                                                           real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
-    const double *msg = (by_parity && st->r_parity) ? msg1 : msg0;
     real *dst[kEdgeVecs] = {v0, v1, v2};
     for (int side = 0; side < 2; side++) {
         const int nb = side == 0 ? sh.rank - 1 : sh.rank + 1;          // neighbour
@@ -693,7 +685,7 @@ constexpr long long kP2pTimeoutTicks = 300000000;   // 3 s of the 100 MHz wall c
 __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restrict__ pt, int mi, unsigned long long epoch, XState *__restrict__ st, int it,
                                                         TileShard sh, int edgeN, int KP, int nvec,
                                                         real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
-    if (it >= 0 && st->stop_it < it) return;    // launch `it` did nothing (the CG had stopped): no message, on any rank
+    if (it >= 0 && st->stop_it <= it) return;   // launch `it` left no message (the CG stopped at or before it): on every rank alike
     __shared__ int failed;
     const int tid = threadIdx.x;
     if (tid == 0) failed = st->p2p_error;
@@ -748,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     const int np_in = sh.nbt;                                // records of the previous launch: every tile of the problem
     real *vs = reinterpret_cast<real *>(hv_smem);
     double *rs = reinterpret_cast<double *>(hv_smem + (((size_t)rowsV * KP * sizeof(real) + 15) / 16 * 16));
-    const int RPITCH = hv_res_pitch(k);
+    constexpr int RPITCH = KQ;                              // = hv_res_pitch(k)
     real *rn = reinterpret_cast<real *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * RPITCH * sizeof(double) + 15) / 16 * 16));
     double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rn) + (((size_t)TI * KP * sizeof(real) + 15) / 16 * 16));
     real *thp = reinterpret_cast<real *>(thd + (size_t)nlag * KP);
@@ -934,51 +926,12 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             if (four) dst[3] = a3;
         }
     };
-    if (CG && stopped) {
-        // The CLOSING launch (the stop test fired at the top of iteration `it`, or `it` is the iteration cap): s and r of the
-        // last completed iteration are finalised for the tile's own rows, and what used to be a separate pass over the
-        // vectors happens here as well -- w_new = w + s and the per-tile sums <g,s>, <s,r>, <s,s> of the acceptance test
-        // (rf_tron.h:183-190).  The gradient and the iterate are only read by this one launch of the solve.
-        const __amdgpu_buffer_rsrc_t g_own = buffer_rsrc(a.g + (size_t)i0 * KP, own_bytes);
-        const __amdgpu_buffer_rsrc_t w_own = buffer_rsrc(a.w + (size_t)i0 * KP, own_bytes);
-        const __amdgpu_buffer_rsrc_t wn_own = buffer_rsrc(a.w_new + (size_t)i0 * KP, own_bytes);
-        double gs = 0, srr = 0, ss = 0;
-        auto closing = [&](int e, real x, real rx, real hx, real sx, real gx, real wx) {
-            const int eo = e - Hh * KP;
-            if ((uint32_t)eo >= own_n) return;
-            real rnew, snew;
-            if (MODE == HV_CG_FIRST) { rnew = -x; snew = 0; }              // the gradient already met the tolerance: s = 0
-            else { snew = fma(alpha, x, sx); rnew = fma(nalpha, hx, rx); } // rf_tron.h:461, 489-490
-            buffer_store_real(s_rsrc, eo * sz, snew);
-            buffer_store_real(ro_rsrc, eo * sz, rnew);
-            buffer_store_real(wn_own, eo * sz, wx + snew);                 // rf_tron.h:183-184
-            gs += (double)gx * (double)snew; srr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
-            if (edge_tile) edge_put(0, i0 * KP + eo, snew);
-        };
-        real gv[kHvOperandRegs], wv[kHvOperandRegs];
-#pragma unroll
-        for (int m = 0; m < kHvOperandRegs; m++) {
-            gv[m] = MODE == HV_CG_FIRST ? vr[m] : buffer_load_real(g_own, obyte0 + 256 * m * sz);
-            wv[m] = buffer_load_real(w_own, obyte0 + 256 * m * sz);
-        }
-#pragma unroll
-        for (int m = 0; m < kHvOperandRegs; m++)
-            closing(tid + 256 * m, vr[m], MODE == HV_CG_STEP ? rv[m] : real(0), MODE == HV_CG_STEP ? hr[m] : real(0),
-                    MODE == HV_CG_STEP ? sr[m] : real(0), gv[m], wv[m]);
-#pragma nounroll
-        for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256) {
-            const int vb = vbyte0 + (e - tid) * sz, ob = obyte0 + (e - tid) * sz;
-            const real x = buffer_load_real(v_rsrc, vb);
-            closing(e, x, MODE == HV_CG_STEP ? buffer_load_real(r_rsrc, vb) : real(0),
-                    MODE == HV_CG_STEP ? buffer_load_real(h_rsrc, vb) : real(0),
-                    MODE == HV_CG_STEP ? buffer_load_real(s_rsrc, ob) : real(0),
-                    MODE == HV_CG_FIRST ? x : buffer_load_real(g_own, ob), buffer_load_real(w_own, ob));
-        }
-        block_allsum3(gs, srr, ss, smem);
-        if (tid == 0) put_record(4, gs, srr, ss, 0, false);
-        if (p2p) __threadfence_system();
-        return;
-    }
+    // The launch that detects the stop (at the top of iteration `it`, or `it` is the iteration cap) does nothing more: the
+    // last completed iteration is closed -- s += alpha d, w_new = w + s, the sums of the acceptance test -- by
+    // cg_close_kernel, which the host enqueues after the CG launches.  (Closing it here, as round 2 did for s and r and an
+    // earlier round-3 version did for everything, keeps six more vectors' worth of state alive next to the Gram slice: the
+    // kernel spilled and every CG launch became 3 us slower.)
+    if (MODE == HV_CG_STEP && stopped) return;
 
     // (1) operand rows -> LDS (zeros outside [0,T) stay zeros through every update below)
     double ar2 = 0, vv = 0, dot = 0, lq = 0, rhd = 0, hh = 0;
@@ -1015,6 +968,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
                 MODE == HV_CG_STEP ? buffer_load_real(h_rsrc, vb) : real(0),
                 MODE == HV_CG_STEP ? buffer_load_real(s_rsrc, ob) : real(0));
     }
+    if (MODE == HV_CG_FIRST && stopped) return;             // the gradient already meets the tolerance: s = 0 is written, no product
 #if defined(TRMF_HV_ABL) && (TRMF_HV_ABL & 2)
     const bool ar_on = false;
 #else
@@ -1301,20 +1255,75 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
     }
 }
 
+// ---- closing the CG of the fused path (rf_tron.h:460-461, 183-190) ---------------------------------------------------
+// The CG launches stop at the top of iteration `stop_it` without touching anything.  This kernel closes iteration
+// stop_it - 1: alpha = rho / <d,Hd> from that launch's records (same fixed-order sum as a CG launch makes),
+// s += alpha d, r' = r - alpha Hd (needed only for <s,r'>), w_new = w + s, and the per-tile sums <g,s>, <s,r'>, <s,s>
+// into fields [4..6] of the records of the gradient / plain message; with several ranks also the first / last midx rows of
+// s (edge vector 0).  One workgroup per tile, own rows only; stop_it = 0 (the gradient met the tolerance): s = 0.
+template <bool SHARD>
+__global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *__restrict__ st, TileShard sh, int TI,
+                                                      const double *__restrict__ msg_even, const double *__restrict__ msg_odd,
+                                                      const real *__restrict__ d_even, const real *__restrict__ d_odd,
+                                                      const real *__restrict__ r_even, const real *__restrict__ r_odd,
+                                                      const real *__restrict__ h_even, const real *__restrict__ h_odd,
+                                                      real *__restrict__ s, const real *__restrict__ g, const real *__restrict__ w,
+                                                      real *__restrict__ w_new, double *__restrict__ rec_out,
+                                                      const PeerTable *__restrict__ pt) {
+    __shared__ double smem[256];
+    const int tid = threadIdx.x, it = st->stop_it, KP = p.KP, Hh = p.midx;
+    const int tile = (SHARD ? sh.tile0 : 0) + (int)blockIdx.x;
+    const int i0 = tile * TI, i1 = min(i0 + TI, p.T);
+    real alpha = 0;
+    const int par = (it - 1) & 1;
+    if (it >= 1) {                                      // uniform: every workgroup (and rank) sees the same stop_it
+        const double *msg = par ? msg_odd : msg_even;
+        double dHd = 0;
+        for (int i = tid; i < sh.nbt; i += 256) dHd += msg[rec_index<SHARD>(sh, i)];
+        dHd = block_allsum(dHd, smem);
+        alpha = (real)st->rho_hist[it - 1] / (real)dHd;                     // rf_tron.h:460
+    }
+    const real *dv = par ? d_odd : d_even, *rv = par ? r_odd : r_even, *hv = par ? h_odd : h_even;
+    const bool p2p = SHARD && pt != nullptr;
+    const int edgeN = Hh * KP;
+    real *edges_lo = SHARD ? edge_base(p2p && sh.rank > 0 ? pt->msg[2][sh.rank - 1] : rec_out, sh, sh.rank) : nullptr;
+    real *edges_hi = SHARD ? edge_base(p2p && sh.rank + 1 < sh.world ? pt->msg[2][sh.rank + 1] : rec_out, sh, sh.rank) : nullptr;
+    double gs = 0, sr = 0, ss = 0;
+    for (int e = i0 * KP + tid; e < i1 * KP; e += 256) {
+        real snew = s[e], rnew;
+        if (it >= 1) { snew = fma(alpha, dv[e], snew); rnew = fma(-alpha, hv[e], rv[e]); s[e] = snew; }   // rf_tron.h:461, 489-490
+        else rnew = r_even[e];                          // s = 0 and r = -g as the first launch left them
+        w_new[e] = w[e] + snew;                         // rf_tron.h:183-184
+        gs += (double)g[e] * (double)snew; sr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
+        if (SHARD) {
+            const uint32_t lo = (uint32_t)(e - sh.row_b * KP), hi = (uint32_t)(e - (sh.row_e - Hh) * KP);
+            if (lo < (uint32_t)edgeN) edges_lo[lo] = snew;
+            if (hi < (uint32_t)edgeN) edges_hi[(size_t)kEdgeVecs * edgeN + hi] = snew;
+        }
+    }
+    block_allsum3(gs, sr, ss, smem);
+    if (tid == 0) {
+        const size_t ri = rec_index<SHARD>(sh, tile) + 4;
+        for (int r = 0; r < (p2p ? sh.world : 1); r++) {
+            double *dst = (p2p ? pt->msg[2][r] : rec_out) + ri;
+            dst[0] = gs; dst[1] = sr; dst[2] = ss;
+        }
+    }
+    if (p2p) __threadfence_system();
+}
+
 // ---- acceptance test and commit of the fused path: sums of the per-tile records -----------------------------------
-// <g,s>, <s,r>, <s,s> come from the closing launch's message (msg0 / msg1 by XState::r_parity), <s,Hs> from the plain
-// launch's; with several ranks a rank commits its own timestamps [row_b, row_e) (the rows of W are all-gathered next).
-__global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msg0,
-                                                          const double *__restrict__ msg1, const double *__restrict__ msgP,
+// <g,s>, <s,r>, <s,s> (cg_close_kernel) and <s,Hs> (plain launch) sit in the same records; with several ranks a rank
+// commits its own timestamps [row_b, row_e) (the rows of W are all-gathered next).
+__global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msgP,
                                                           TileShard sh, int sharded, const real *__restrict__ w_new,
                                                           real *__restrict__ w, XState *__restrict__ log_x,
                                                           double *__restrict__ log_norms) {
     __shared__ double smem[256];
-    const double *msgC = st->r_parity ? msg1 : msg0;
     double gs_d = 0, sr_d = 0, ss_d = 0, sHs = 0;
     for (int i = threadIdx.x; i < sh.nbt; i += 256) {
         const size_t ri = sharded ? rec_index<true>(sh, i) : rec_index<false>(sh, i);
-        gs_d += msgC[ri + 4]; sr_d += msgC[ri + 5]; ss_d += msgC[ri + 6]; sHs += msgP[ri + 2];
+        gs_d += msgP[ri + 4]; sr_d += msgP[ri + 5]; ss_d += msgP[ri + 6]; sHs += msgP[ri + 2];
     }
     block_allsum3(gs_d, sr_d, ss_d, smem);
     sHs = block_allsum(sHs, smem);

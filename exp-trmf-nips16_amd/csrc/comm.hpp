@@ -119,6 +119,14 @@ struct SelfComm : Comm {
     int allgather_slots(void *, size_t, hipStream_t) override { return 0; }
 };
 
+// Measurement aid: rank r of a world of N with NO peers -- every gather is skipped.  A session under it runs exactly the
+// kernels rank r would run (its item rows, its timestamps, its tiles) with the GPU to itself, so their times are a rank's
+// compute share undisturbed by other processes; the factors it produces are NOT a solution (the other ranks' blocks are stale).
+struct SoloComm : Comm {
+    int allgatherv(void *, const uint64_t *, hipStream_t) override { return 0; }
+    int allgather_slots(void *, size_t, hipStream_t) override { return 0; }
+};
+
 struct CallbackComm : Comm {
     trmf_allgatherv_fn fn = nullptr;
     void *ctx = nullptr;

@@ -978,14 +978,10 @@ struct TrmfSessionImpl {
             return 0;
         }
         if (comm->allgather_slots(xm[mi], (size_t)tsh_rank.slot_dbl * sizeof(double), stream)) return kFail;
-        if (nvec > 0) unpack_halo(xm[mi], xm[mi], 0, nvec, v0, v1, v2);
+        if (nvec > 0 && edgeN > 0)
+            hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, xm[mi],
+                               tsh_rank, edgeN, KP, nvec, v0, v1, v2);
         return 0;
-    }
-    void unpack_halo(const double *m0, const double *m1, int by_parity, int nvec, real *v0, real *v1, real *v2) {
-        const int edgeN = midx * KP;
-        if (edgeN == 0) return;
-        hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, m0, m1,
-                           xstate.p, by_parity, tsh_rank, edgeN, KP, nvec, v0, v1, v2);
     }
     // The fused X-solve: gradient launch, CG launches (one per iteration, the closing one also forms w_new and the sums
     // of the acceptance test), plain launch H s, accept.  shard: every launch runs this rank's tiles only and is
@@ -1002,7 +998,6 @@ struct TrmfSessionImpl {
         if (shard && exchange(2, -1, 1, g.p, nullptr, nullptr)) return kFail;
         a = HvVecs{};
         a.v = g.p; a.s = s.p; a.d_out = dbuf[0]; a.r_out = rbuf[0]; a.out = hbuf[0];
-        a.g = g.p; a.w = W.p; a.w_new = w_new.p;
         launch_hv_tile<HV_CG_FIRST>(shard, a, 0, 0, mg, mc[0]);                // f, |g|, cgtol; s = 0, r = d = -g; H d
         if (shard && exchange(0, 0, 3, dbuf[0], rbuf[0], hbuf[0])) return kFail;
         // host-followed progress only where an exchange costs a collective; peer to peer (and on one rank) the launches of
@@ -1024,14 +1019,22 @@ struct TrmfSessionImpl {
                 upto = std::min(maxcg, upto + 2);
             } else if (it == maxcg) cg_pred = maxcg;
         }
-        if (shard) unpack_halo(mc[0], mc[1], 1, 1, s.p, nullptr, nullptr);     // halo of s from the closing launch's message
+        // close the last completed iteration: s, w_new = w + s, the sums of the acceptance test (+ the edge rows of s)
+        const TileShard &sh = shard ? tsh_rank : tsh;
+        const PeerTable *pt = (shard && p2p.on) ? peer_table.p : nullptr;
+        if (shard)
+            hipLaunchKernelGGL(cg_close_kernel<true>, dim3(sh.ntiles), dim3(256), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
+                               dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
+        else
+            hipLaunchKernelGGL(cg_close_kernel<false>, dim3(sh.ntiles), dim3(256), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
+                               dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
+        if (shard && exchange(2, -1, 1, s.p, nullptr, nullptr)) return kFail;   // halo rows of s
         a = HvVecs{};
         a.v = s.p; a.out = hbuf[0];
-        launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs>
+        launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs> (fields [0..2] of the same records)
         if (shard && exchange(2, -1, 0, nullptr, nullptr, nullptr)) return kFail;
-        const TileShard &sh = shard ? tsh_rank : tsh;
         const int nb = (int)std::min<size_t>(kMaxPartials, ((size_t)(sh.row_e - sh.row_b) * KP + 255) / 256);
-        hipLaunchKernelGGL(accept_tile_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mc[0], mc[1], mg, sh,
+        hipLaunchKernelGGL(accept_tile_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mg, sh,
                            shard ? 1 : 0, w_new.p, W.p, log_x, log_n);
         TRMF_HIP_CHECK(hipGetLastError());
         if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W

@@ -307,6 +307,14 @@ int32_t trmf_dist_init_callback(int32_t rank, int32_t world, trmf_allgatherv_fn 
     return 0;
 }
 
+int32_t trmf_dist_init_solo(int32_t rank, int32_t world) {
+    if (world < 1 || rank < 0 || rank >= world || world > kMaxWorld) { set_error("bad rank/world"); return kFail; }
+    std::shared_ptr<SoloComm> c = std::make_shared<SoloComm>();
+    c->rank = rank; c->world = world;
+    g_comm = std::move(c);
+    return 0;
+}
+
 int32_t trmf_dist_rank(void) { return active_comm()->rank; }
 int32_t trmf_dist_world(void) { return active_comm()->world; }
 void trmf_dist_finalize(void) { g_comm.reset(); }

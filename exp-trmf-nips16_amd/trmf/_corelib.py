@@ -55,7 +55,9 @@ class corelib(object):
             threads, int(missing), verbose)
 
 
-corelib_path = path.join(path.dirname(path.abspath(__file__)), 'corelib/')
+# TRMF_CORELIB_DIR: load the library pair from another directory (the sanitizer build of `make asan`)
+import os as _os
+corelib_path = _os.environ.get('TRMF_CORELIB_DIR') or path.join(path.dirname(path.abspath(__file__)), 'corelib/')
 soname = 'trmf'
 _clib = None
 

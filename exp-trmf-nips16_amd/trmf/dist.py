@@ -90,6 +90,15 @@ def init_host_staged(dtype=np.float32, group=None):
     return rank, world
 
 
+def init_solo(rank, world, dtype=np.float32):
+    """Measurement aid: rank ``rank`` of ``world`` with no peers (gathers skipped) -- a rank's compute share alone on
+    the GPU; the factors a session produces under it are not a solution."""
+    lib = session.lib_for(dtype)
+    if lib.trmf_dist_init_solo(int(rank), int(world)) != 0:
+        raise RuntimeError(lib.trmf_last_error().decode())
+    return rank, world
+
+
 def finalize(dtype=None):
     """Drop the library communicator(s).  Sessions created under one keep it alive until they are closed."""
     for dt in _dtypes(dtype):

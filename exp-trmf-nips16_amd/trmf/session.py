@@ -60,6 +60,7 @@ def bind(lib):
     lib.trmf_dist_init.argtypes = [c_int32, c_int32, c_void_p]; lib.trmf_dist_init.restype = c_int32
     lib.trmf_dist_init_callback.argtypes = [c_int32, c_int32, ALLGATHERV_FN, c_void_p]
     lib.trmf_dist_init_callback.restype = c_int32
+    lib.trmf_dist_init_solo.argtypes = [c_int32, c_int32]; lib.trmf_dist_init_solo.restype = c_int32
     lib.trmf_dist_rank.restype = c_int32
     lib.trmf_dist_world.restype = c_int32
     lib.trmf_dist_finalize.restype = None

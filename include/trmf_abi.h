@@ -196,6 +196,10 @@ typedef int32_t (*trmf_allgatherv_fn)(void *buf, const uint64_t *offsets, int32_
                                       void *ctx);
 TRMF_API int32_t trmf_dist_init_callback(int32_t rank, int32_t world, trmf_allgatherv_fn allgatherv,
                                 void *ctx);
+/* Measurement aid: act as rank `rank` of `world` WITHOUT peers (every gather is skipped).  A session created under it
+ * runs exactly the kernels that rank would run, alone on the GPU -- its times are that rank's compute share; the factors
+ * are NOT a solution (the other ranks' blocks stay stale).  Used by scripts/shard_compute_times.py. */
+TRMF_API int32_t trmf_dist_init_solo(int32_t rank, int32_t world);
 TRMF_API int32_t trmf_dist_rank(void);
 TRMF_API int32_t trmf_dist_world(void);
 TRMF_API void trmf_dist_finalize(void);

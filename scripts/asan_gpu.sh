@@ -1,0 +1,11 @@
+#!/bin/bash
+# Host-side ASan + UBSan run of the library (make -C exp-trmf-nips16_amd asan) on a GPU box: the ABI tests, the golden parity
+# cases and the session life cycle (create / run / append_rows / destroy) under the sanitizers.  usage: scripts/asan_gpu.sh <outfile>
+R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/.. && pwd)}
+OUT=${1:-/dev/stdout}
+RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
+cd $R
+TRMF_CORELIB_DIR=$R/exp-trmf-nips16_amd/build/asan LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0 \
+  UBSAN_OPTIONS=print_stacktrace=1 timeout 1500 python -m pytest tests/test_abi.py tests/test_gpu_parity.py tests/test_python_frontend.py -m gpu -x -q > $OUT 2>&1
+echo "asan pytest exit $?" >> $OUT
+grep -c "ERROR: AddressSanitizer\|runtime error:" $OUT
