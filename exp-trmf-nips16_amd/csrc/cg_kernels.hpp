@@ -863,6 +863,10 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     constexpr int KA = (KQ * VEC * (int)sizeof(real) / 4 <= kHvGramUpfront) ? KQ : kHvGramUpfront / (VEC * (int)sizeof(real) / 4);
     GramVec<VEC> gq[KQ];
     const __amdgpu_buffer_rsrc_t g_rsrc = buffer_rsrc(G + (size_t)i0 * p.gstride, 0x7fffffff);
+    // (Measured and rejected in round 3: reading only the UPPER triangle -- blocks below the thread's own loaded as their
+    // mirror G[t0 + u][VEC jq ..] and transposed in registers -- halves the HBM stream of a launch (64 -> 35 MB at config 3) and is
+    // bit-identical, but a mirror load touches VEC different Gram rows per thread instead of one: the wavefront's requests fall
+    // into 4x as many cache lines and the launch went from 14.3 to 20.2 us.)
     const int g_voff = (int)(((uint32_t)(min(i0 + lrc, T - 1) - i0) * (uint32_t)p.gstride + (uint32_t)t0) * sizeof(real));
     const int rowbytes = k * (int)sizeof(real);
     int g_soff = 0;
@@ -1274,8 +1278,19 @@ __global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *
     const int tid = threadIdx.x, it = st->stop_it, KP = p.KP, Hh = p.midx;
     const int tile = (SHARD ? sh.tile0 : 0) + (int)blockIdx.x;
     const int i0 = tile * TI, i1 = min(i0 + TI, p.T);
+    const int par = it >= 1 ? (it - 1) & 1 : 0;         // it == 0: r = -g sits in the even buffer, d and H d are not used
+    const real *dv = par ? d_odd : d_even, *rv = par ? r_odd : r_even, *hv = par ? h_odd : h_even;
+    // the tile's own elements are requested BEFORE the records are summed (the loads do not depend on alpha): a thread
+    // keeps up to kPer of them in registers, longer tiles go through the loop below
+    constexpr int kPer = 6;
+    const int e0 = i0 * KP + tid, e1 = i1 * KP;
+    real xd[kPer], xh[kPer], xr[kPer], xs[kPer], xg[kPer], xw[kPer];
+#pragma unroll
+    for (int m = 0; m < kPer; m++) {
+        const int e = min(e0 + 256 * m, e1 - 1);
+        xd[m] = dv[e]; xh[m] = hv[e]; xr[m] = rv[e]; xs[m] = s[e]; xg[m] = g[e]; xw[m] = w[e];
+    }
     real alpha = 0;
-    const int par = (it - 1) & 1;
     if (it >= 1) {                                      // uniform: every workgroup (and rank) sees the same stop_it
         const double *msg = par ? msg_odd : msg_even;
         double dHd = 0;
@@ -1283,24 +1298,26 @@ __global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *
         dHd = block_allsum(dHd, smem);
         alpha = (real)st->rho_hist[it - 1] / (real)dHd;                     // rf_tron.h:460
     }
-    const real *dv = par ? d_odd : d_even, *rv = par ? r_odd : r_even, *hv = par ? h_odd : h_even;
     const bool p2p = SHARD && pt != nullptr;
     const int edgeN = Hh * KP;
     real *edges_lo = SHARD ? edge_base(p2p && sh.rank > 0 ? pt->msg[2][sh.rank - 1] : rec_out, sh, sh.rank) : nullptr;
     real *edges_hi = SHARD ? edge_base(p2p && sh.rank + 1 < sh.world ? pt->msg[2][sh.rank + 1] : rec_out, sh, sh.rank) : nullptr;
     double gs = 0, sr = 0, ss = 0;
-    for (int e = i0 * KP + tid; e < i1 * KP; e += 256) {
-        real snew = s[e], rnew;
-        if (it >= 1) { snew = fma(alpha, dv[e], snew); rnew = fma(-alpha, hv[e], rv[e]); s[e] = snew; }   // rf_tron.h:461, 489-490
-        else rnew = r_even[e];                          // s = 0 and r = -g as the first launch left them
-        w_new[e] = w[e] + snew;                         // rf_tron.h:183-184
-        gs += (double)g[e] * (double)snew; sr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
+    auto close_elem = [&](int e, real dx, real hx, real rx, real sx, real gx, real wx) {
+        real snew = sx, rnew = rx;                      // it == 0: s = 0 and r = -g as the first launch left them
+        if (it >= 1) { snew = fma(alpha, dx, sx); rnew = fma(-alpha, hx, rx); s[e] = snew; }   // rf_tron.h:461, 489-490
+        w_new[e] = wx + snew;                           // rf_tron.h:183-184
+        gs += (double)gx * (double)snew; sr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
         if (SHARD) {
             const uint32_t lo = (uint32_t)(e - sh.row_b * KP), hi = (uint32_t)(e - (sh.row_e - Hh) * KP);
             if (lo < (uint32_t)edgeN) edges_lo[lo] = snew;
             if (hi < (uint32_t)edgeN) edges_hi[(size_t)kEdgeVecs * edgeN + hi] = snew;
         }
-    }
+    };
+#pragma unroll
+    for (int m = 0; m < kPer; m++)
+        if (e0 + 256 * m < e1) close_elem(e0 + 256 * m, xd[m], xh[m], xr[m], xs[m], xg[m], xw[m]);
+    for (int e = e0 + 256 * kPer; e < e1; e += 256) close_elem(e, dv[e], hv[e], rv[e], s[e], g[e], w[e]);
     block_allsum3(gs, sr, ss, smem);
     if (tid == 0) {
         const size_t ri = rec_index<SHARD>(sh, tile) + 4;
