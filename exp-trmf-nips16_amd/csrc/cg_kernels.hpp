@@ -198,7 +198,10 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
                                                              const uint32_t *__restrict__ lag_set,
                                                              const uint32_t *__restrict__ steps, int nsteps,
                                                              const real *__restrict__ theta,
-                                                             real *__restrict__ base, double *__restrict__ Pbase, int TI) {
+                                                             real *__restrict__ base, double *__restrict__ Pbase, int TI,
+                                                             int tile0) {
+    // tile0: index of the first time tile of this launch (a rank of the time-sharded unfused CG launches its own tiles only);
+    // the partial sums go to slot (tile index) * gridDim.y + column group, so that a rank's slots are one contiguous range
     extern __shared__ __attribute__((aligned(16))) unsigned char ar_smem[];
     __shared__ double smem[48];
     constexpr bool STEP = MODE == AR_CG_STEP;
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
     double *rs = reinterpret_cast<double *>(ar_smem + (one_pass ? 0 : vbytes));
     real *ths = reinterpret_cast<real *>(ar_smem + (one_pass ? (vbytes > rbytes ? vbytes : rbytes) : vbytes + rbytes));   // ths[l][col]
     if (STEP && st->stop_it < it) return;               // an EARLIER launch ended the CG
-    const int i0 = blockIdx.x * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
+    const int i0 = (blockIdx.x + tile0) * TI, i1 = min(i0 + TI, T), c0 = blockIdx.y * kArCols;
     // The workgroup is a serial chain  partial sums -> alpha, beta -> operand rows -> residuals -> adjoint: the operand
     // loads do not depend on the scalars, so the first batch is requested before anything else (and every later batch
     // before the previous one is processed).
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
     ar2 = block_allsum_wide(ar2, smem);
     vv = block_allsum_wide(vv, smem);
     if (tid == 0) {
-        const size_t slot = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        const size_t slot = (size_t)(blockIdx.x + tile0) * gridDim.y + blockIdx.y;
         Pbase[P_AR * (size_t)p.pstride + slot] = ar2;
         Pbase[P_VV * (size_t)p.pstride + slot] = vv;
     }
@@ -662,6 +665,21 @@ __device__ __forceinline__ int xcd_contiguous_tile(int b, int n) {
     const int x = b % kXcds, i = b / kXcds;
     const int base = n / kXcds, extra = n % kXcds;           // XCDs 0..extra-1 get base+1 workgroups
     return x * base + min(x, extra) + i;
+}
+
+// This rank's first / last midx rows of up to three vectors -> its slot of an edge message (the time-sharded UNFUSED CG: its
+// kernels do not export edges themselves; hv_tile_kernel and cg_close_kernel do).
+__global__ __launch_bounds__(256) void edge_pack_kernel(double *__restrict__ msg, TileShard sh, int edgeN, int KP, int nvec,
+                                                        const real *__restrict__ v0, const real *__restrict__ v1,
+                                                        const real *__restrict__ v2) {
+    const real *src[kEdgeVecs] = {v0, v1, v2};
+    real *edges = edge_base(msg, sh, sh.rank);
+    for (int side = 0; side < 2; side++) {
+        const size_t row0 = side == 0 ? (size_t)sh.row_b * KP : (size_t)sh.row_e * KP - edgeN;
+        for (int v = 0; v < nvec; v++)
+            for (int e = blockIdx.x * 256 + threadIdx.x; e < edgeN; e += gridDim.x * 256)
+                edges[((size_t)side * kEdgeVecs + v) * edgeN + e] = src[v][row0 + e];
+    }
 }
 
 // ---- peer-to-peer form of the exchange (TRMF_CG=p2p) ---------------------------------------------------------------------
@@ -1145,7 +1163,7 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
                                                       double *__restrict__ Pbase, int np_base,
                                                       int np_dot, const real *__restrict__ g,
                                                       real *__restrict__ s, real *__restrict__ r,
-                                                      real *__restrict__ d) {
+                                                      real *__restrict__ d, size_t e_begin, size_t e_end) {
     __shared__ double smem[256];
     const double ar2 = sum_partials(Pbase + P_AR * (size_t)p.pstride, np_base, smem);
     const double vv = sum_partials(Pbase + P_VV * (size_t)p.pstride, np_base, smem);
@@ -1170,8 +1188,8 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
         st->stop_it = stopped ? 0 : kCgRunning;
         st->r_parity = 0;
     }
-    const size_t N = (size_t)p.T * p.KP;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+    // elements [e_begin, e_end): everything, or a rank's timestamps plus the halo rows whose gradient it has been sent
+    for (size_t e = e_begin + (size_t)blockIdx.x * 256 + threadIdx.x; e < e_end; e += (size_t)gridDim.x * 256) {
         const real gv = g[e];
         s[e] = 0; r[e] = -gv; d[e] = -gv;
     }
@@ -1185,12 +1203,11 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__re
                                                    const real *__restrict__ r_even,
                                                    const real *__restrict__ r_odd,
                                                    real *__restrict__ w_new,
-                                                   double *__restrict__ Pbase) {
+                                                   double *__restrict__ Pbase, size_t e_begin, size_t e_end, int slot0) {
     __shared__ double smem[256];
-    const real *__restrict__ r = st->r_parity ? r_odd : r_even;   // fused CG: the launch that stopped wrote it
-    const size_t N = (size_t)p.T * p.KP;
+    const real *__restrict__ r = st->r_parity ? r_odd : r_even;   // the launch that stopped wrote it
     double gs = 0, sr = 0, ss = 0;
-    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256) {
+    for (size_t e = e_begin + (size_t)blockIdx.x * 256 + threadIdx.x; e < e_end; e += (size_t)gridDim.x * 256) {
         const real sv = s[e];
         w_new[e] = w[e] + sv;
         gs += (double)g[e] * (double)sv;
@@ -1199,9 +1216,9 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__re
     }
     block_allsum3(gs, sr, ss, smem);
     if (threadIdx.x == 0) {
-        Pbase[P_GS * (size_t)p.pstride + blockIdx.x] = gs;
-        Pbase[P_SR * (size_t)p.pstride + blockIdx.x] = sr;
-        Pbase[P_SS * (size_t)p.pstride + blockIdx.x] = ss;
+        Pbase[P_GS * (size_t)p.pstride + slot0 + blockIdx.x] = gs;
+        Pbase[P_SR * (size_t)p.pstride + slot0 + blockIdx.x] = sr;
+        Pbase[P_SS * (size_t)p.pstride + slot0 + blockIdx.x] = ss;
     }
 }
 
@@ -1216,7 +1233,8 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
                                                      int np_dot, const double *__restrict__ Prr_final,
                                                      const real *__restrict__ w_new,
                                                      real *__restrict__ w,
-                                                     XState *__restrict__ log_x, double *__restrict__ log_norms) {
+                                                     XState *__restrict__ log_x, double *__restrict__ log_norms,
+                                                     size_t e_begin, size_t e_end) {
     __shared__ double smem[256];
     const double gs = (double)(real)sum_partials(Pbase + P_GS * (size_t)p.pstride, np, smem);
     const double sr = (double)(real)sum_partials(Pbase + P_SR * (size_t)p.pstride, np, smem);
@@ -1230,8 +1248,7 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
     const double fnew = f - actred;
     const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
     if (accept) {
-        const size_t N = (size_t)p.T * p.KP;
-        for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < N; e += (size_t)gridDim.x * 256)
+        for (size_t e = e_begin + (size_t)blockIdx.x * 256 + threadIdx.x; e < e_end; e += (size_t)gridDim.x * 256)
             w[e] = w_new[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {          // fields no block reads in this kernel

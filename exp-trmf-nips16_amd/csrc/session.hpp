@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <initializer_list>
 #include <memory>
 #include <vector>
 
@@ -454,8 +455,7 @@ struct TrmfSessionImpl {
                 xbounds[r] = (uint64_t)T * r / comm->world;
             }
         }
-        decide_cg_shard();
-        return 0;
+        return decide_cg_shard();
     }
 
     // Message buffers of the fused path and the tile partition of the time-sharded CG: rank r owns
@@ -794,8 +794,8 @@ struct TrmfSessionImpl {
                                Yr_val.p, H.p, Wv, lossrow.p, rb, re, (uint32_t)n);
     }
     int gram_x(bool timeshard = false) {
-        if (timeshard) {            // time-sharded CG: a rank only ever reads the Grams / right-hand sides of its own tiles
-            const uint32_t rb = (uint32_t)tsh_rank.row_b, re = (uint32_t)tsh_rank.row_e;
+        if (timeshard || uts) {     // time-sharded CG: a rank only ever reads the Grams / right-hand sides of its own timestamps
+            const uint32_t rb = (uint32_t)(uts ? ush.row_b : tsh_rank.row_b), re = (uint32_t)(uts ? ush.row_e : tsh_rank.row_e);
             switch (NT) {
                 case 1: launch_gram_x<1>(rb, re); break;
                 case 2: launch_gram_x<2>(rb, re); break;
@@ -1066,15 +1066,76 @@ struct TrmfSessionImpl {
     // replicated at the sizes it covers.  TRMF_CG=shard|replicate overrides.
     bool cg_shard = false;
     int apply_slots = 1;         // partial-sum slots (= workgroups of apply_kernel) per rank when sharded
-    void decide_cg_shard() {
-        cg_shard = false;
+    // Time-sharded UNFUSED CG (round 3): like the fused path's, a rank owns a contiguous block of AR
+    // tiles -- its timestamps -- and runs every kernel of the solve on that block only: ar_tile_kernel (vector updates, AR
+    // operator), apply_kernel (cached-Gram product), the element-wise kernels.  Per step the ranks exchange the midx first /
+    // last rows of d, r and H d (edge_pack_kernel -> one all-gather of equal slots -> halo_unpack_kernel) and their slots of
+    // the partial-sum arrays, in one grouped round; nothing T-sized is gathered (the sharded Gram product above gathers the
+    // rows of H d, T KP values, every step).  The host follows the CG's stop as in the fused path.
+    bool uts = false;
+    TileShard ush{};                          // rank / world / rows / edge-slot geometry (no records: the unfused kernels keep arrays)
+    std::vector<uint64_t> ubounds;            // AR-tile-aligned timestamp partition
+    DevBuf<double> umsg;                      // edge message: world slots of 2 sides x 3 vectors x midx rows
+    int u_tile0 = 0, u_ntiles = 0, u_tpr = 0, wn_slots = 1;
+    int decide_cg_shard() {
+        cg_shard = false; uts = false;
         apply_slots = std::max(1, std::min(nba, kMaxPartials / std::max(1, comm->world)));
-        if (comm->world <= 1 || tile_TI > 0 || full) return;
-        const double N = comm->world, sz = sizeof(real);
+        const int W_ = comm->world;
+        if (W_ <= 1 || tile_TI > 0 || full) return 0;
+        const char *e = getenv("TRMF_CG");
+        const int tiles = (T + ar_TI - 1) / ar_TI, tpr = (tiles + W_ - 1) / W_;
+        const long long last_rows = (long long)T - (long long)(W_ - 1) * tpr * ar_TI;
+        const bool can_uts = (long long)(W_ - 1) * tpr < tiles && (long long)tpr * ar_TI >= midx && last_rows >= std::max(midx, 1) &&
+                             (long long)tiles * (KP / kArCols) <= xp.pstride;
+        if (can_uts && !(e && (e[0] == 's' || e[0] == 'r'))) {
+            uts = true;
+            u_tpr = tpr; u_tile0 = comm->rank * tpr; u_ntiles = std::min(tiles, (comm->rank + 1) * tpr) - u_tile0;
+            ubounds.assign(W_ + 1, (uint64_t)T);
+            for (int r = 0; r < W_; r++) ubounds[r] = (uint64_t)std::min<long long>(T, (long long)r * tpr * ar_TI);
+            ush = TileShard{};
+            ush.rank = comm->rank; ush.world = W_; ush.row_b = (int)ubounds[comm->rank]; ush.row_e = (int)ubounds[comm->rank + 1];
+            const size_t edge_bytes = (size_t)2 * kEdgeVecs * midx * KP * sizeof(real);
+            ush.edge_off_dbl = 0; ush.slot_dbl = (unsigned)((edge_bytes + 15) / 16 * 2);
+            wn_slots = std::max(1, std::min(nbe, kMaxPartials / W_));
+            if (umsg.alloc((size_t)W_ * std::max(1u, ush.slot_dbl))) return kFail;
+            return 0;
+        }
+        const double N = W_, sz = sizeof(real);
         const double t_saved = (double)T * k * k * sz * (1.0 - 1.0 / N) / 4e12;
         const double t_gather = 40e-6 + (double)T * KP * sz * (1.0 - 1.0 / N) / ((N - 1.0) * 50e9);
         cg_shard = t_saved > 2.0 * t_gather;
-        if (const char *e = getenv("TRMF_CG")) cg_shard = (e[0] == 's');
+        if (e && (e[0] == 's' || e[0] == 'r')) cg_shard = (e[0] == 's');
+        return 0;
+    }
+    // one grouped exchange of the time-sharded unfused CG: edge rows of nvec vectors + this rank's slots of partial arrays
+    // (kind 0: apply_kernel's slots, 1: ar_tile_kernel's, 2: wnew_kernel's)
+    struct PartialRef { int slot, kind; };
+    int uts_exchange(int nvec, real *v0, real *v1, real *v2, std::initializer_list<PartialRef> arrays) {
+        const int W_ = comm->world, edgeN = midx * KP;
+        const bool edges = nvec > 0 && edgeN > 0;
+        if (edges)
+            hipLaunchKernelGGL(edge_pack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, umsg.p, ush, edgeN, KP,
+                               nvec, v0, v1, v2);
+        std::vector<uint64_t> off[3];
+        for (int kind = 0; kind < 3; kind++) {
+            off[kind].resize(W_ + 1);
+            for (int r = 0; r <= W_; r++) {
+                const uint64_t slots = kind == 0 ? (uint64_t)r * apply_slots
+                                     : kind == 1 ? (uint64_t)std::min<long long>((long long)r * u_tpr, (T + ar_TI - 1) / ar_TI) * (KP / kArCols)
+                                                 : (uint64_t)r * wn_slots;
+                off[kind][r] = slots * sizeof(double);
+            }
+        }
+        if (comm->group_begin()) return kFail;
+        int rc = edges ? comm->allgather_slots(umsg.p, (size_t)ush.slot_dbl * sizeof(double), stream) : 0;
+        for (const PartialRef &a : arrays)
+            if (rc == 0) rc = comm->allgatherv(P(a.slot), off[a.kind].data(), stream);
+        if (comm->group_end()) return kFail;
+        if (rc) return rc;
+        if (edges)
+            hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, umsg.p, ush, edgeN,
+                               KP, nvec, v0, v1, v2);
+        return 0;
     }
     // Unfused path (long lag sets): one operator application = ar_tile_kernel (AR + ridge part -> arbase) followed by
     // apply_kernel (+ cached-Gram product, dot-product partials).
@@ -1085,15 +1146,16 @@ struct TrmfSessionImpl {
     int hv(const ArVecs &av, int cg_it, int last, int minus_b, real *out, int dot_mode) {
         XState *st = xstate.p;
         double *Pb = partials.p;
-        const dim3 ar_grid((T + ar_TI - 1) / ar_TI, KP / kArCols);
+        const dim3 ar_grid(uts ? u_ntiles : (T + ar_TI - 1) / ar_TI, KP / kArCols);
+        const int ar_tile0 = uts ? u_tile0 : 0;
         const size_t ar_lds = ar_tile_lds_bytes(ar_TI, midx, nlag);
-        const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
+        const int ndot = (cg_shard || uts) ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
         if (cg_it >= 1)
             hipLaunchKernelGGL((ar_tile_kernel<AR_CG_STEP>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, av, ndot, cg_it, last,
-                               lag_set.p, lag_steps.p, nsteps, theta.p, arbase.p, Pb, ar_TI);
+                               lag_set.p, lag_steps.p, nsteps, theta.p, arbase.p, Pb, ar_TI, ar_tile0);
         else
             hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), ar_grid, dim3(kArThreads), ar_lds, stream, xp, st, av, ndot, 0, 0,
-                               lag_set.p, lag_steps.p, nsteps, theta.p, arbase.p, Pb, ar_TI);
+                               lag_set.p, lag_steps.p, nsteps, theta.p, arbase.p, Pb, ar_TI, ar_tile0);
         if (last) return 0;                                              // the closing launch has no product
         const real *operand = cg_it >= 1 ? av.d_out : av.v;
         const real *resid = cg_it >= 1 ? av.r_out : av.r_in;
@@ -1110,6 +1172,19 @@ struct TrmfSessionImpl {
             }
 #undef TRMF_LAUNCH_APPLY_SHARED
             return 0;
+        }
+        if (uts) {
+            // this rank's timestamps only; then one grouped exchange: the edge rows the next kernel stages as halo and the
+            // rank's slots of the partial sums
+            hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
+                               Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, ush.row_b, ush.row_e - ush.row_b,
+                               comm->rank * apply_slots);
+            TRMF_HIP_CHECK(hipGetLastError());
+            const int c0 = P_CG0 + 3 * (cg_it & 1);
+            if (cg_it >= 1) return uts_exchange(3, av.d_out, av.r_out, out, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
+            if (cg_it == 0) return uts_exchange(1, out, nullptr, nullptr, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
+            if (minus_b) return uts_exchange(1, out, nullptr, nullptr, {{P_DOT, 0}, {P_LQ, 0}, {P_AR, 1}, {P_VV, 1}});   // gradient
+            return uts_exchange(0, nullptr, nullptr, nullptr, {{P_DOT, 0}});                                              // H s
         }
         if (!cg_shard) {
             hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
@@ -1167,27 +1242,45 @@ struct TrmfSessionImpl {
             return 0;
         }
         real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
-        const int ndot = cg_shard ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
+        const int ndot = (cg_shard || uts) ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
+        // element ranges of the element-wise kernels: everything, or (time-sharded) this rank's timestamps -- cg_init_kernel
+        // also covers the halo rows, whose gradient the exchange after the gradient product has delivered
+        const size_t NV = (size_t)T * KP;
+        const size_t own_b = uts ? (size_t)ush.row_b * KP : 0, own_e = uts ? (size_t)ush.row_e * KP : NV;
+        const size_t halo_b = uts ? (size_t)std::max(0, ush.row_b - midx) * KP : 0, halo_e = uts ? (size_t)std::min(T, ush.row_e + midx) * KP : NV;
+        const int nbw = uts ? wn_slots : nbe, npw = uts ? comm->world * wn_slots : nbe;
         ArVecs av{};
         av.v = W.p;
         if (hv(av, -1, 0, 1, g.p, 0)) return kFail;                      // gradient, <g,g>, AR/ridge sums
         hipLaunchKernelGGL(cg_init_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbar, ndot, g.p,
-                           s.p, rbuf[0], dbuf[0]);                       // f, |g|, cgtol, rho[0]; s = 0, r = d = -g
+                           s.p, rbuf[0], dbuf[0], halo_b, halo_e);       // f, |g|, cgtol, rho[0]; s = 0, r = d = -g
         av = ArVecs{};
         av.v = dbuf[0]; av.r_in = rbuf[0];
         if (hv(av, 0, 0, 0, hbuf[0], 1)) return kFail;                   // H d0 and its three dot products
+        int upto = uts ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
         for (int it = 1; it <= maxcg; it++) {                            // launch `maxcg` only closes the last iteration
             av.v = dbuf[(it - 1) & 1]; av.r_in = rbuf[(it - 1) & 1]; av.hd_in = hbuf[(it - 1) & 1];
             av.s = s.p; av.d_out = dbuf[it & 1]; av.r_out = rbuf[it & 1];
             if (hv(av, it, it == maxcg ? 1 : 0, 0, hbuf[it & 1], 1)) return kFail;
+            if (!uts) continue;
+            if (it == upto && it < maxcg) {                              // time-sharded: follow the stop (identical on every rank)
+                int stop = kCgRunning;
+                TRMF_HIP_CHECK(hipMemcpyAsync(&stop, &xstate.p->stop_it, sizeof(int), hipMemcpyDeviceToHost, stream));
+                TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+                if (stop != kCgRunning) { cg_pred = stop; break; }
+                upto = std::min(maxcg, upto + 2);
+            } else if (it == maxcg) cg_pred = maxcg;
         }
-        hipLaunchKernelGGL(wnew_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1], w_new.p, Pb);
+        hipLaunchKernelGGL(wnew_kernel, dim3(nbw), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1], w_new.p, Pb, own_b, own_e,
+                           uts ? comm->rank * wn_slots : 0);
+        if (uts && uts_exchange(1, s.p, nullptr, nullptr, {{P_GS, 2}, {P_SR, 2}, {P_SS, 2}})) return kFail;
         av = ArVecs{};
         av.v = s.p;
         if (hv(av, -1, 0, 0, hbuf[0], 1)) return kFail;                  // H s, <s,Hs>
-        hipLaunchKernelGGL(accept_kernel, dim3(nbe), dim3(256), 0, stream, xp, st, Pb, nbe, ndot, (const double *)nullptr, w_new.p,
-                           W.p, log_x, log_n);
+        hipLaunchKernelGGL(accept_kernel, dim3(nbw), dim3(256), 0, stream, xp, st, Pb, npw, ndot, (const double *)nullptr, w_new.p,
+                           W.p, log_x, log_n, own_b, own_e);
         TRMF_HIP_CHECK(hipGetLastError());
+        if (uts && gather_rows(W.p, ubounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return 0;
     }
 
@@ -1332,7 +1425,7 @@ struct TrmfSessionImpl {
             av.v = W.p;
             hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), dim3((T + ar_TI - 1) / ar_TI, KP / kArCols), dim3(kArThreads),
                                ar_tile_lds_bytes(ar_TI, midx, nlag), stream, xp, st, av, 0, 0, 0, lag_set.p, lag_steps.p, nsteps,
-                               theta.p, arbase.p, partials.p, ar_TI);
+                               theta.p, arbase.p, partials.p, ar_TI, 0);
         }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_AR), nbar, &st->gs);
         const double ar = host_double(&st->gs);

@@ -169,6 +169,33 @@ def test_two_ranks_one_gpu_config4_shape_replicated_cg():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 4])
+def test_time_sharded_unfused_cg(world, monkeypatch):
+    """The UNFUSED CG (long lag sets; forced here with TRMF_NO_HV_TILE) sharded over time: every kernel of the solve runs on the
+    rank's own block of AR tiles, per step the ranks exchange midx edge rows of d, r, H d and their slots of the partial-sum
+    arrays -- nothing T-sized.  All ranks bit-identical to each other; equal to the single-process unfused run up to the
+    grouping of the partial sums (fp64 1e-9, fp32 1e-3), same CG counts."""
+    import dist_worker
+    from trmf import session, synth
+    iters = 3
+    env = {'TRMF_NO_HV_TILE': '1'}
+    out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c4', env))
+    p, m0 = dist_worker._problem('c4')
+    monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
+    for dtype in (np.float32, np.float64):
+        name = np.dtype(dtype).name
+        model, cg1 = _single_process(p, m0, dtype, iters)
+        W0, H0, T0, cg0 = out[0][name][:4]
+        for r in range(1, world):
+            W, H, Th, cg = out[r][name][:4]
+            assert np.array_equal(W0, W) and np.array_equal(H0, H) and np.array_equal(T0, Th) and cg0 == cg
+        tol = 1e-9 if dtype == np.float64 else 1e-3
+        assert relfro(W0, model.W) < tol and relfro(H0, model.H) < tol and relfro(T0, model.lag_val) < 10 * tol
+        assert all(abs(a - b) <= (0 if dtype == np.float64 else 1) for a, b in zip(cg0, cg1))
+        assert out[0][name][4]      # second session under the same communicator
+
+
+@pytest.mark.gpu
 def test_two_ranks_one_gpu_sharded_cg_gram_product(monkeypatch):
     """The sharded form of the CG (unfused path: every rank multiplies its own timestamps' cached Grams, the rows of
     H d and the partial sums are all-gathered each step): both ranks bit-identical to each other, and
