@@ -439,7 +439,10 @@ struct TrmfSessionImpl {
             nbar = ((T + ar_TI - 1) / ar_TI) * (KP / kArCols);
             if (arbase.alloc(NV)) return kFail;
         }
-        xp.pstride = std::max(kMaxPartials, std::max(nbt, nbar));
+        // with several ranks the apply kernel's partial slots are divided among them: kShardSlots in all, so that a rank's
+        // share of the rows still launches enough workgroups to stream its Grams at full rate (128 of 1024 slots per rank
+        // on 8 GPUs ran config 5's product at half the bandwidth)
+        xp.pstride = std::max(std::max(kMaxPartials, comm->world > 1 ? kShardSlots : 0), std::max(nbt, nbar));
         if (partials.alloc((size_t)P_NSLOTS * xp.pstride)) return kFail;
         xp.T = T; xp.k = k; xp.KP = KP; xp.NT = NT; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
@@ -1065,6 +1068,7 @@ struct TrmfSessionImpl {
     // step (latency ~40 us + bytes over the rank's xGMI links); the fused one-launch-per-step path is faster
     // replicated at the sizes it covers.  TRMF_CG=shard|replicate overrides.
     bool cg_shard = false;
+    static constexpr int kShardSlots = 4096;
     int apply_slots = 1;         // partial-sum slots (= workgroups of apply_kernel) per rank when sharded
     // Time-sharded UNFUSED CG (round 3): like the fused path's, a rank owns a contiguous block of AR
     // tiles -- its timestamps -- and runs every kernel of the solve on that block only: ar_tile_kernel (vector updates, AR
@@ -1079,7 +1083,7 @@ struct TrmfSessionImpl {
     int u_tile0 = 0, u_ntiles = 0, u_tpr = 0, wn_slots = 1;
     int decide_cg_shard() {
         cg_shard = false; uts = false;
-        apply_slots = std::max(1, std::min(nba, kMaxPartials / std::max(1, comm->world)));
+        apply_slots = std::max(1, std::min(nba, kShardSlots / std::max(1, comm->world)));
         const int W_ = comm->world;
         if (W_ <= 1 || tile_TI > 0 || full) return 0;
         const char *e = getenv("TRMF_CG");
