@@ -32,7 +32,10 @@ struct Comm {
     bool call_when_single = false;   // issue the (degenerate) gather even for world == 1
     virtual ~Comm() {}
     // Gather in place: rank r owns bytes [off[r], off[r+1]) of dbuf (device memory).
-    virtual int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) = 0;
+    int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) { return allgatherv_ranges(dbuf, off, off + 1, stream); }
+    // The same with an arbitrary (disjoint) byte range [begin[r], end[r]) per rank -- e.g. the first half of every rank's
+    // block, gathered while the second half is still being computed.
+    virtual int allgatherv_ranges(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) = 0;
     // Several gathers issued between group_begin() and group_end() may be fused into one transfer round.
     virtual int group_begin() { return 0; }
     virtual int group_end() { return 0; }
@@ -43,17 +46,17 @@ struct Comm {
 
 // ---- equal-slot staging shared by the communicators -----------------------------------------------
 constexpr int kMaxWorld = 64;
-struct GatherOffsets { uint64_t off[kMaxWorld + 1]; };
-// block (x, r): bytes [off[r], off[r+1]) of the result come from slot r of the staging buffer; VEC bytes per thread
+struct GatherOffsets { uint64_t b[kMaxWorld], e[kMaxWorld]; };
+// block (x, r): bytes [b[r], e[r]) of the result come from slot r of the staging buffer; VEC bytes per thread
 template <typename V>
 __global__ __launch_bounds__(256) void gather_unpack_kernel(const unsigned char *__restrict__ stage,
                                                             unsigned char *__restrict__ dbuf, GatherOffsets o,
                                                             uint64_t slot, int rank) {
     const int r = blockIdx.y;
     if (r == rank) return;
-    const uint64_t n = (o.off[r + 1] - o.off[r]) / sizeof(V);
+    const uint64_t n = (o.e[r] - o.b[r]) / sizeof(V);
     const V *src = reinterpret_cast<const V *>(stage + (uint64_t)r * slot);
-    V *dst = reinterpret_cast<V *>(dbuf + o.off[r]);
+    V *dst = reinterpret_cast<V *>(dbuf + o.b[r]);
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = src[i];
 }
 struct StagePool {
@@ -63,14 +66,20 @@ struct StagePool {
     std::deque<Buf> bufs;                    // stable addresses: gathers of an open group keep pointers into it
     ~StagePool() { for (Buf &b : bufs) (void)hipFree(b.p); }
     Buf *acquire(size_t bytes, hipStream_t stream) {
+        // a free buffer this stream used last (reuse on one stream is ordered by the stream itself) ...
         for (Buf &b : bufs)
-            if (!b.busy && b.cap >= bytes) {
-                // another stream used the buffer last (a previous session under this communicator): wait for the whole
-                // device -- set-up path, once per session -- instead of synchronising a handle that may be destroyed
-                if (b.last != stream && hipDeviceSynchronize() != hipSuccess) { set_error("device synchronisation failed"); return nullptr; }
-                b.last = stream;             // reuse on one stream is ordered by the stream itself
-                return &b;
-            }
+            if (!b.busy && b.cap >= bytes && b.last == stream) return &b;
+        // ... else, while the pool is small, a fresh one (two streams of one session -- the F-solve's overlapped gather -- keep
+        // their own buffers and never wait for each other) ...
+        if (bufs.size() >= 8)
+            for (Buf &b : bufs)
+                if (!b.busy && b.cap >= bytes) {
+                    // ... else one another stream used last (a previous session under this communicator): wait for the whole
+                    // device -- set-up path -- instead of synchronising a handle that may be destroyed
+                    if (hipDeviceSynchronize() != hipSuccess) { set_error("device synchronisation failed"); return nullptr; }
+                    b.last = stream;
+                    return &b;
+                }
         Buf b{nullptr, (bytes + 4095) / 4096 * 4096, false, stream};
         if (hipMalloc((void **)&b.p, b.cap) != hipSuccess) { set_error("hipMalloc of a gather staging buffer failed"); return nullptr; }
         bufs.push_back(b);
@@ -80,27 +89,28 @@ struct StagePool {
 struct StagedGather {                       // one gather between pack and unpack
     unsigned char *dbuf; GatherOffsets o; uint64_t slot; StagePool::Buf *buf; hipStream_t stream;
 };
-inline uint64_t gather_slot_bytes(const uint64_t *off, int world) {
+inline uint64_t gather_slot_bytes(const uint64_t *begin, const uint64_t *end, int world) {
     uint64_t slot = 0;
-    for (int r = 0; r < world; r++) slot = std::max<uint64_t>(slot, off[r + 1] - off[r]);
+    for (int r = 0; r < world; r++) slot = std::max<uint64_t>(slot, end[r] - begin[r]);
     return (slot + 15) / 16 * 16;
 }
-inline int gather_pack(StagedGather &g, void *dbuf, const uint64_t *off, int rank, int world, StagePool &pool, hipStream_t stream) {
+inline int gather_pack(StagedGather &g, void *dbuf, const uint64_t *begin, const uint64_t *end, int rank, int world, StagePool &pool,
+                       hipStream_t stream) {
     if (world > kMaxWorld) { set_error("more ranks than the staged gather supports"); return kFail; }
-    g.dbuf = (unsigned char *)dbuf; g.slot = gather_slot_bytes(off, world); g.stream = stream;
-    for (int r = 0; r <= world; r++) g.o.off[r] = off[r];
+    g.dbuf = (unsigned char *)dbuf; g.slot = gather_slot_bytes(begin, end, world); g.stream = stream;
+    for (int r = 0; r < world; r++) { g.o.b[r] = begin[r]; g.o.e[r] = end[r]; }
     g.buf = nullptr;
     if (g.slot == 0) return 0;                  // nothing anywhere: the callers stop here
     g.buf = pool.acquire(g.slot * world, stream);
     if (!g.buf) return kFail;
-    const uint64_t mine = off[rank + 1] - off[rank];
-    if (mine) TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + (uint64_t)rank * g.slot, g.dbuf + off[rank], mine, hipMemcpyDeviceToDevice, stream));
+    const uint64_t mine = end[rank] - begin[rank];
+    if (mine) TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + (uint64_t)rank * g.slot, g.dbuf + begin[rank], mine, hipMemcpyDeviceToDevice, stream));
     return 0;
 }
 inline int gather_unpack(const StagedGather &g, int rank, int world) {
     uint64_t align = (uint64_t)(uintptr_t)g.dbuf, most = 0;
-    for (int r = 0; r <= world; r++) align |= g.o.off[r];
-    for (int r = 0; r < world; r++) if (r != rank) most = std::max<uint64_t>(most, g.o.off[r + 1] - g.o.off[r]);
+    for (int r = 0; r < world; r++) align |= g.o.b[r] | g.o.e[r];
+    for (int r = 0; r < world; r++) if (r != rank) most = std::max<uint64_t>(most, g.o.e[r] - g.o.b[r]);
     if (most == 0) return 0;
     const int vec = (align % 16 == 0) ? 16 : (align % 8 == 0) ? 8 : (align % 4 == 0) ? 4 : 1;
     const dim3 grid((unsigned)std::min<uint64_t>(1024, (most / vec + 255) / 256), (unsigned)world);
@@ -115,7 +125,7 @@ inline int gather_unpack(const StagedGather &g, int rank, int world) {
 }
 
 struct SelfComm : Comm {
-    int allgatherv(void *, const uint64_t *, hipStream_t) override { return 0; }
+    int allgatherv_ranges(void *, const uint64_t *, const uint64_t *, hipStream_t) override { return 0; }
     int allgather_slots(void *, size_t, hipStream_t) override { return 0; }
 };
 
@@ -123,7 +133,7 @@ struct SelfComm : Comm {
 // kernels rank r would run (its item rows, its timestamps, its tiles) with the GPU to itself, so their times are a rank's
 // compute share undisturbed by other processes; the factors it produces are NOT a solution (the other ranks' blocks are stale).
 struct SoloComm : Comm {
-    int allgatherv(void *, const uint64_t *, hipStream_t) override { return 0; }
+    int allgatherv_ranges(void *, const uint64_t *, const uint64_t *, hipStream_t) override { return 0; }
     int allgather_slots(void *, size_t, hipStream_t) override { return 0; }
 };
 
@@ -132,11 +142,11 @@ struct CallbackComm : Comm {
     void *ctx = nullptr;
     std::vector<unsigned char> host;
     StagePool pool;
-    int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) override {
+    int allgatherv_ranges(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) override {
         StagedGather g;
-        if (gather_pack(g, dbuf, off, rank, world, pool, stream)) return kFail;
+        if (gather_pack(g, dbuf, begin, end, rank, world, pool, stream)) return kFail;
         if (g.slot == 0) return 0;
-        const uint64_t total = g.slot * world, mine = off[rank + 1] - off[rank];
+        const uint64_t total = g.slot * world, mine = end[rank] - begin[rank];
         if (host.size() < total) host.resize(total);
         std::vector<uint64_t> eq(world + 1);
         for (int r = 0; r <= world; r++) eq[r] = (uint64_t)r * g.slot;
@@ -145,8 +155,8 @@ struct CallbackComm : Comm {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         if (fn(host.data(), eq.data(), world, ctx) != 0) { set_error("allgatherv callback failed"); return kFail; }
         for (int r = 0; r < world; r++) {
-            if (r == rank || off[r + 1] == off[r]) continue;
-            TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + eq[r], host.data() + eq[r], off[r + 1] - off[r], hipMemcpyHostToDevice, stream));
+            if (r == rank || end[r] == begin[r]) continue;
+            TRMF_HIP_CHECK(hipMemcpyAsync(g.buf->p + eq[r], host.data() + eq[r], end[r] - begin[r], hipMemcpyHostToDevice, stream));
         }
         if (gather_unpack(g, rank, world)) return kFail;
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
@@ -239,20 +249,22 @@ struct RcclComm : Comm {
         if (rc != 0) { set_error(std::string("RCCL group failed: ") + rccl_api().GetErrorString(rc)); return kFail; }
         return bad ? kFail : 0;
     }
-    int allgatherv(void *dbuf, const uint64_t *off, hipStream_t stream) override {
+    int allgatherv_ranges(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) override {
         RcclApi &api = rccl_api();
         constexpr int kNcclInt8 = 0;                     // ncclInt8 / ncclChar
-        if (by_broadcast) return allgatherv_broadcast(dbuf, off, stream);
+        if (by_broadcast) return allgatherv_broadcast(dbuf, begin, end, stream);
         // Equal slots cost world x (largest block) of staging per gather in flight.  With a very skewed partition (row
         // counts of an nnz-balanced split can differ widely) that can be several times the gathered data itself: beyond
         // 4x the payload (and 64 MiB) the in-place form -- one broadcast per owner, no extra memory -- is used instead.
         {
-            const uint64_t stage = gather_slot_bytes(off, world) * (uint64_t)world, payload = off[world] - off[0];
-            if (stage > 4 * payload && stage > (64ull << 20)) return allgatherv_broadcast(dbuf, off, stream);
+            uint64_t payload = 0;
+            for (int r = 0; r < world; r++) payload += end[r] - begin[r];
+            const uint64_t stage = gather_slot_bytes(begin, end, world) * (uint64_t)world;
+            if (stage > 4 * payload && stage > (64ull << 20)) return allgatherv_broadcast(dbuf, begin, end, stream);
         }
         // equal slots, one collective: in place in the staging buffer (send = own slot of the receive buffer)
         StagedGather g;
-        if (gather_pack(g, dbuf, off, rank, world, pool, stream)) return kFail;
+        if (gather_pack(g, dbuf, begin, end, rank, world, pool, stream)) return kFail;
         if (g.slot == 0) return 0;
         const int rc = api.AllGather(g.buf->p + (uint64_t)rank * g.slot, g.buf->p, g.slot, kNcclInt8, comm, stream);
         if (rc != 0) { set_error(std::string("RCCL all-gather failed: ") + api.GetErrorString(rc)); return kFail; }
@@ -266,14 +278,14 @@ struct RcclComm : Comm {
         if (rc != 0) { set_error(std::string("RCCL all-gather failed: ") + api.GetErrorString(rc)); return kFail; }
         return 0;
     }
-    int allgatherv_broadcast(void *dbuf, const uint64_t *off, hipStream_t stream) {
+    int allgatherv_broadcast(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) {
         RcclApi &api = rccl_api();
         constexpr int kNcclInt8 = 0;
         int rc = in_group ? 0 : api.GroupStart();
         for (int r = 0; r < world && rc == 0; r++) {
-            const uint64_t bytes = off[r + 1] - off[r];
+            const uint64_t bytes = end[r] - begin[r];
             if (bytes == 0) continue;
-            char *p = (char *)dbuf + off[r];
+            char *p = (char *)dbuf + begin[r];
             rc = api.Broadcast(p, p, bytes, kNcclInt8, r, comm, stream);
         }
         if (!in_group) { const int rc2 = api.GroupEnd(); if (rc == 0) rc = rc2; }

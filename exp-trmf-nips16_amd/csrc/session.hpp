@@ -153,6 +153,8 @@ struct TrmfSessionImpl {
         }
         for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2, ts0, ts1}) if (ev) (void)hipEventDestroy(ev);
         release_p2p();
+        for (hipEvent_t ev : {ov_a, ov_b}) if (ev) (void)hipEventDestroy(ev);
+        if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
     void release_p2p() {
@@ -448,7 +450,7 @@ struct TrmfSessionImpl {
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
         xp.full = full ? 1 : 0; xp.gstride = full ? 0 : (size_t)k * k; xp.trYTY = trYTY;
 
-        fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1);
+        fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1); fmid.clear();
         if (!dense) {
             partition_by_nnz<uint64_t>((uint64_t)n, host_col_ptr.data(), comm->world, fbounds.data());
             partition_by_nnz<uint64_t>((uint64_t)T, host_row_ptr.data(), comm->world, xbounds.data());
@@ -756,6 +758,19 @@ struct TrmfSessionImpl {
     }
     int fs_mode = kShardMeasure, fs_calls = 0;
     hipEvent_t fs0 = nullptr, fs1 = nullptr, fs2 = nullptr;
+    // Overlapped all-gather of H (large item factors: config 5's is 512 MB): the rank's rows are solved in two launches of
+    // equal nnz; the first halves of every rank's block are gathered on a side stream while the second launch runs, the
+    // second halves follow on the solver stream, which then waits for the side stream.  Below kOverlapBytes per rank the
+    // second launch's tail costs more than the gather it hides (config 4).  TRMF_FOVERLAP=1|0 forces it on / off.
+    static constexpr uint64_t kOverlapBytes = 16ull << 20;
+    hipStream_t side = nullptr;
+    hipEvent_t ov_a = nullptr, ov_b = nullptr;
+    std::vector<uint64_t> fmid;               // per rank: the row that splits its block's nnz in two
+    bool overlap_h(uint32_t rows) {
+        if (comm->world <= 1 || full || host_col_ptr.empty()) return false;
+        if (const char *e = getenv("TRMF_FOVERLAP")) return e[0] == '1';
+        return (uint64_t)rows * KP * sizeof(real) >= kOverlapBytes;
+    }
     int fsolve(PhaseEvents &ev) {
         // the SECOND call is the measured one: the first carries one-time costs on both sides of the comparison (code
         // object load of the kernel, connection set-up inside the first collective)
@@ -767,6 +782,39 @@ struct TrmfSessionImpl {
         const bool replicate = fs_mode == kShardOff, measure = fs_mode == kShardMeasure && fs_calls == 1;
         const uint32_t rb = replicate ? 0u : (uint32_t)fbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)n : (uint32_t)fbounds[comm->rank + 1];
+        if (fs_mode == kShardOn && overlap_h(re - rb)) {
+            const int W_ = comm->world;
+            if (!side) {
+                TRMF_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+                TRMF_HIP_CHECK(hipEventCreateWithFlags(&ov_a, hipEventDisableTiming));
+                TRMF_HIP_CHECK(hipEventCreateWithFlags(&ov_b, hipEventDisableTiming));
+            }
+            if ((int)fmid.size() != W_) {
+                fmid.resize(W_);
+                for (int r = 0; r < W_; r++) {
+                    const uint64_t half = (host_col_ptr[fbounds[r]] + host_col_ptr[fbounds[r + 1]]) / 2;
+                    fmid[r] = (uint64_t)(std::lower_bound(host_col_ptr.begin() + fbounds[r], host_col_ptr.begin() + fbounds[r + 1], half) -
+                                         host_col_ptr.begin());
+                }
+            }
+            const uint32_t rm = (uint32_t)fmid[comm->rank];
+            const uint64_t rowbytes = (uint64_t)KP * sizeof(real);
+            std::vector<uint64_t> b1(W_), e1(W_), b2(W_), e2(W_);
+            for (int r = 0; r < W_; r++) { b1[r] = fbounds[r] * rowbytes; e1[r] = fmid[r] * rowbytes; b2[r] = e1[r]; e2[r] = fbounds[r + 1] * rowbytes; }
+            TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+            if (launch_fsolve_rows(rb, rm)) return kFail;
+            TRMF_HIP_CHECK(hipEventRecord(ov_a, stream));
+            if (launch_fsolve_rows(rm, re)) return kFail;
+            TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+            TRMF_HIP_CHECK(hipGetLastError());
+            fs_calls++;
+            TRMF_HIP_CHECK(hipStreamWaitEvent(side, ov_a, 0));
+            if (comm->allgatherv_ranges(H.p, b1.data(), e1.data(), side)) return kFail;      // first halves, under the second launch
+            TRMF_HIP_CHECK(hipEventRecord(ov_b, side));
+            if (comm->allgatherv_ranges(H.p, b2.data(), e2.data(), stream)) return kFail;    // second halves
+            TRMF_HIP_CHECK(hipStreamWaitEvent(stream, ov_b, 0));
+            return 0;
+        }
         if (measure) TRMF_HIP_CHECK(hipEventRecord(fs0, stream));
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
         if (launch_fsolve_rows(rb, re)) return kFail;

@@ -76,7 +76,7 @@ def _single_process(p, m0, dtype, iters):
 @pytest.mark.gpu
 @pytest.mark.parametrize('world,shape,mode', [(2, 'small', 'timeshard'), (2, 'odd', 'timeshard'), (2, 'c4', 'timeshard'),
                                               (4, 'c4', 'timeshard'), (8, 'c4', 'timeshard'), (3, 'c4', 'measure'),
-                                              (4, 'c4', 'replicate'), (2, 'small', 'p2p'), (2, 'c4', 'p2p'), (4, 'c4', 'p2p'),
+                                              (4, 'c4', 'replicate'), (3, 'c4', 'overlap'), (2, 'odd', 'overlap'), (2, 'small', 'p2p'), (2, 'c4', 'p2p'), (4, 'c4', 'p2p'),
                                               (8, 'c4', 'p2p')])
 def test_time_sharded_cg_matches_single_process(world, shape, mode):
     """The CG sharded over TIME: every rank runs the tiles of its own block of timestamps, the tile
@@ -86,10 +86,13 @@ def test_time_sharded_cg_matches_single_process(world, shape, mode):
     runs iterations 1-2 replicated and 3-4 time-sharded, then decides: 5 iterations cover the switch both ways).
     'p2p': the peer-to-peer form of the exchange -- every rank's kernels write their tile records and edge rows straight
     into the other ranks' IPC-mapped message buffers and synchronise through flag words (bounded waits); here the "peers"
-    are processes sharing the one GPU, the code path (IPC handles, remote stores, system-scope flags) is the multi-GPU one."""
+    are processes sharing the one GPU, the code path (IPC handles, remote stores, system-scope flags) is the multi-GPU one.
+    'overlap': the all-gather of H split in two (ranges per rank) behind the two halves of the F-solve, forced on at these sizes."""
     import dist_worker
     iters = 5 if mode == 'measure' else 3
     env = {} if mode == 'measure' else {'TRMF_CG': mode}
+    if mode == 'overlap':       # the F-solve in two launches, the first halves of H gathered on a side stream under the second
+        env = {'TRMF_FOVERLAP': '1', 'TRMF_FSHARD': 'shard', 'TRMF_CG': 'timeshard'}
     out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, shape, env))
     p, m0 = dist_worker._problem(shape)
     for dtype in (np.float32, np.float64):
