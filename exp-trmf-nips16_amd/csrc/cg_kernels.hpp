@@ -699,7 +699,7 @@ struct PeerTable {                              // lives in device memory (index
     unsigned long long *flags[3][kMaxPeers];    // message m's flag words (one 64-byte line per source rank) in the arena of rank r
 };
 constexpr int kFlagStride = 8;                  // 64 bytes between the flags of different source ranks
-constexpr long long kP2pTimeoutTicks = 300000000;   // 3 s of the 100 MHz wall clock
+constexpr long long kP2pTimeoutTicks = 1000000000;  // 10 s of the 100 MHz wall clock
 __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restrict__ pt, int mi, unsigned long long epoch, XState *__restrict__ st, int it,
                                                         TileShard sh, int edgeN, int KP, int nvec,
                                                         real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
