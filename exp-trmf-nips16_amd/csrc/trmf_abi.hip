@@ -9,6 +9,7 @@
 
 #include <memory>
 #include <mutex>
+#include <random>
 
 #include "session.hpp"
 
@@ -145,12 +146,32 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
         fprintf(stdout, "\n");
         fflush(stdout);
     }
-    // Quirk Q1: with warm_start == 0 the reference rebuilds W, H and lag_val as private random
-    // matrices of matching shapes BEFORE its dimension check (trmf.cpp:547-558, 719-722), trains those and discards
-    // them: the caller's arrays come back unchanged and no "[ERR MSG]" line can appear.  Reproduced as far as a caller
-    // can observe it: nothing is validated, trained or written (the ">> iter" lines of the discarded run are not
-    // reproduced).
-    if (!warm_start) return;
+    // Quirk Q1: with warm_start == 0 the reference rebuilds W, H and lag_val as PRIVATE random matrices of
+    // matching shapes before its dimension check (trmf_initialization, trmf.cpp:547-558, 719-722: rng_t = std::mt19937 seeded 0,
+    // a fresh uniform_real_distribution<double>(0,1) / normal_distribution<double>(0,1) per element, cast to val_type,
+    // rf_matrix.h:56-68, 740-753), trains those -- its ">> iter" lines under verbose describe that run -- and discards them:
+    // the caller's arrays come back unchanged and no "[ERR MSG]" about the caller's shapes can appear.  Same here: the same
+    // generator calls in the same order produce the same starting point (libstdc++ on both sides), the training runs on the
+    // device on private copies, and nothing is written back.
+    std::vector<real> cold_W, cold_H, cold_LV;
+    PyMatrix privW, privH, privLV;
+    if (!warm_start) {
+        const size_t m = pyY->rows, n = pyY->cols, k = pyW->cols;
+        std::mt19937 rng(0);
+        cold_W.resize(m * k); cold_H.resize(n * k); cold_LV.resize((size_t)py_lag_size * k);
+        for (real &x : cold_W) x = (real)std::uniform_real_distribution<double>(0.0, 1.0)(rng);
+        for (real &x : cold_H) x = (real)std::uniform_real_distribution<double>(0.0, 1.0)(rng);
+        for (real &x : cold_LV) x = (real)std::normal_distribution<double>(0.0, 1.0)(rng);
+        auto view = [](std::vector<real> &buf, size_t rows, size_t cols, int32_t type) {
+            PyMatrix v{};
+            v.rows = rows; v.cols = cols; v.nnz = rows * cols; v.val = buf.data(); v.type = type;
+            return v;
+        };
+        privW = view(cold_W, m, k, TRMF_DENSE_ROWMAJOR);
+        privH = view(cold_H, n, k, TRMF_DENSE_ROWMAJOR);
+        privLV = view(cold_LV, py_lag_size, k, TRMF_DENSE_COLMAJOR);
+        pyW = &privW; pyH = &privH; pylag_val = &privLV;       // from here on the call works on the private model
+    }
     DeviceGuard guard;                               // device of this library for the call, the caller's afterwards
     TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
                                       lambdaLag, period_W, period_H, period_Lag, missing, verbose);

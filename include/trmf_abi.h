@@ -75,11 +75,14 @@ typedef struct {
  * (trmf.cpp:647-693).  Outputs are written in place; Y and lag_set are never written.
  * Dimension/layout violations print the reference's "[ERR MSG]" lines on stderr and return
  * without touching the outputs (trmf.cpp:561-596,632-634).  warm_start == 0 reproduces the
- * reference's observable behaviour: the reference rebuilds W, H and
- * lag_val as private random matrices of matching shapes before its dimension check
- * (trmf.cpp:547-558), trains those and discards them -- the caller's arrays are not updated
- * and no "[ERR MSG]" line can appear; here the call returns at once (silent, nothing written;
- * the discarded run and its ">> iter" lines are not reproduced).  `threads` is accepted
+ * reference's behaviour: the reference rebuilds W, H and lag_val as
+ * PRIVATE random matrices of matching shapes before its dimension check (trmf.cpp:547-558:
+ * std::mt19937 seeded 0, uniform / normal draws in doubles cast to the element type), trains
+ * those -- the ">> iter" lines under verbose describe that run -- and discards them: the
+ * caller's arrays are not updated and no "[ERR MSG]" about the caller's shapes can appear.
+ * Here the same generator calls give the same private starting point, the training runs on
+ * the device, and nothing is written back (tests/test_abi.py replays a capture of the
+ * reference's lines).  `threads` is accepted
  * and ignored (no OpenMP on the device path).
  *
  * Checks beyond the reference's (each prints one "[ERR MSG]: ..." line and returns like a

@@ -95,24 +95,24 @@ class Mat(object):
         return byref(self.m)
 
 
-def _train_args(Y, lag_set, W, H, theta, hyper, max_iter, periods, threads, missing, verbose):
+def _train_args(Y, lag_set, W, H, theta, hyper, max_iter, periods, threads, missing, verbose, warm_start=1):
     dtype = W.dtype
     mats = (Mat(Y, dtype), Mat(W, dtype), Mat(H, dtype), Mat(theta, dtype))
     lag_set = np.ascontiguousarray(lag_set, dtype=np.uint32)
     args = [mats[0].ref(), lag_set.ctypes.data_as(POINTER(c_uint32)), c_uint32(len(lag_set)),
-            mats[1].ref(), mats[2].ref(), mats[3].ref(), c_int32(1),
+            mats[1].ref(), mats[2].ref(), mats[3].ref(), c_int32(int(warm_start)),
             c_double(hyper['lambdaI']), c_double(hyper['lambdaAR']), c_double(hyper['lambdaLag']),
             c_int32(max_iter), c_int32(periods[0]), c_int32(periods[1]), c_int32(periods[2]),
             c_int32(threads), c_int32(int(missing)), c_int32(verbose)]
     return args, (mats, lag_set)
 
 
-def train_ref(Y, lag_set, W, H, theta, hyper, max_iter=10, periods=(1, 1, 2), threads=4, missing=True, verbose=0):
+def train_ref(Y, lag_set, W, H, theta, hyper, max_iter=10, periods=(1, 1, 2), threads=4, missing=True, verbose=0, warm_start=1):
     """Run the REAL reference c_trmf_train in place on (W, H, theta)."""
     lib = ref(W.dtype)
     if lib is None:
         raise RuntimeError('oracle/_ref not built (run `make -C oracle ref` in the build container)')
-    args, keep = _train_args(Y, lag_set, W, H, theta, hyper, max_iter, periods, threads, missing, verbose)
+    args, keep = _train_args(Y, lag_set, W, H, theta, hyper, max_iter, periods, threads, missing, verbose, warm_start)
     lib.c_trmf_train.restype = None
     lib.c_trmf_train(*args)
     return W, H, theta

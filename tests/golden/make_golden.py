@@ -122,6 +122,32 @@ def make_case(name, n, T, k, lag_set, density, dtype, max_iter, seed=0, hyper=No
         name, T, n, k, Y.nnz, np.dtype(dtype).name, max_iter, cg.tolist(), J, os.path.getsize(path) // 1024))
 
 
+def make_cold_case(name, dtype, n=90, T=120, k=6, lag_set=(1, 2, 5), density=0.2, max_iter=4, seed=9):
+    """warm_start = 0 (quirk Q1): the reference trains a PRIVATE model drawn from its own generator (mt19937 seeded 0,
+    trmf.cpp:547-558) and leaves the caller's arrays alone; what a caller can observe of that run are the ">> iter" norm
+    lines under verbose.  Captured: those lines, and that the caller's arrays came back unchanged."""
+    prob = synth.sparse_problem(n, T, k, 3, density, dtype=dtype, seed=seed)
+    Y = smat.csr_matrix(prob['Y']); Y.sort_indices()
+    lag_set = np.array(sorted(lag_set), dtype=np.uint32)
+    model = synth.initial_model(Y, lag_set, k, seed=seed, dtype=dtype)
+    W0, H0, Th0 = model.W.copy(), model.H.copy(), np.asfortranarray(model.lag_val.copy())
+    W, H, Th = W0.copy(), H0.copy(), np.asfortranarray(Th0.copy())
+    hyper = dict(synth.HYPER)
+    with capture_fds() as cap:
+        O.train_ref(Y, lag_set, W, H, Th, hyper, max_iter=max_iter, threads=2, missing=True, verbose=1, warm_start=0)
+    assert np.array_equal(W, W0) and np.array_equal(H, H0) and np.array_equal(Th, Th0)
+    normF = np.full(max_iter, -1.0); normX = np.full(max_iter, -1.0); normLV = np.full(max_iter, -1.0)
+    for line in cap.err:
+        m = re.match(r'>> iter (\d+) (F|X|LV) (\S+)$', line.strip())
+        if m:
+            {'F': normF, 'X': normX, 'LV': normLV}[m.group(2)][int(m.group(1)) - 1] = float(m.group(3))
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, Y_indptr=Y.indptr.astype(np.int64), Y_indices=Y.indices.astype(np.int32), Y_data=Y.data,
+                        shape=np.array([T, n]), lag_set=lag_set, W0=W0, H0=H0, Th0=Th0, normF=normF, normX=normX, normLV=normLV,
+                        lambdaI=hyper['lambdaI'], lambdaAR=hyper['lambdaAR'], lambdaLag=hyper['lambdaLag'], max_iter=np.array(max_iter))
+    print('{:>14s}: cold start {} F {} X {} LV {}'.format(name, np.dtype(dtype).name, normF.tolist(), normX.tolist(), normLV.tolist()))
+
+
 def main():
     if O.ref(np.float32) is None:
         sys.exit('oracle/_ref is missing: run `make -C oracle ref` first (build container only)')
@@ -138,6 +164,9 @@ def main():
     make_full_case('full_dense_f64', n=37, T=520, k=4, lag_set=[1, 2, 3], dtype=np.float64, max_iter=5, seed=6)
     make_full_case('full_dense_f32', n=60, T=300, k=20, lag_set=[1, 2, 24], dtype=np.float32, max_iter=4, seed=7, order='F')
     make_full_case('full_sparse_f64', n=150, T=200, k=9, lag_set=[0, 1, 5], dtype=np.float64, max_iter=4, seed=8, sparse_density=0.2)
+    if 'cold' in sys.argv or len(sys.argv) == 1:
+        make_cold_case('py_cold_f64', np.float64)
+        make_cold_case('py_cold_f32', np.float32)
 
 
 if __name__ == '__main__':

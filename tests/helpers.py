@@ -54,3 +54,28 @@ TOL = {
     'float64': dict(factor=1e-6, objective=1e-8),
     'float32': dict(factor=1e-3, objective=1e-5),
 }
+
+
+class capture_fds(object):
+    """Capture what C code writes to fd 1 and fd 2 (the libraries print their verbose lines with fprintf)."""
+
+    def __enter__(self):
+        import os
+        import sys
+        import tempfile
+        sys.stdout.flush(); sys.stderr.flush()
+        self.saved = [os.dup(1), os.dup(2)]
+        self.tmp = [tempfile.TemporaryFile(), tempfile.TemporaryFile()]
+        os.dup2(self.tmp[0].fileno(), 1); os.dup2(self.tmp[1].fileno(), 2)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        import os
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(self.saved[0], 1); os.dup2(self.saved[1], 2)
+        self.out, self.err = [], []
+        for t, dst in zip(self.tmp, (self.out, self.err)):
+            t.seek(0); dst.extend(t.read().decode().splitlines()); t.close()
+        for fd in self.saved:
+            os.close(fd)

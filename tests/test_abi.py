@@ -147,8 +147,45 @@ def test_cold_start_is_silent_and_never_writes(capfd):
     lib.c_trmf_train(byref(pyY), lags.ctypes.data_as(POINTER(c_uint32)), 2, byref(pyW), byref(pyH), byref(pyT), 0,
                      0.5, 50.0, 0.5, 2, 1, 1, 2, 1, 1, 0)
     err = capfd.readouterr().err
-    assert '[ERR MSG]' not in err
+    assert 'Y.rows' not in err and 'W.rows' not in err           # nothing about the CALLER's shapes (a box without a GPU says so)
     assert all(np.array_equal(a, get(m)) for a, m in zip(before, (pyW, pyH, pyT)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['py_cold_f64', 'py_cold_f32'])
+def test_cold_start_trains_the_references_private_model(name):
+    """warm_start == 0 against a capture of the reference (tests/golden/make_golden.py: make_cold_case): the reference draws a
+    private model from std::mt19937(0) (trmf.cpp:547-558), trains it, prints the ">> iter i F|X|LV" norms of THAT run under
+    verbose and leaves the caller's arrays untouched.  Same generator calls here => the same starting point => the same lines
+    (printed with %g: 6 digits), and the caller's arrays bit-for-bit unchanged."""
+    import os
+    import re
+    from ctypes import POINTER, byref, c_uint32
+    from helpers import GOLDEN_DIR, capture_fds
+    from trmf import session
+    from trmf.rf_util import PyMatrix
+    z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+    T, n = [int(v) for v in z['shape']]
+    Y = smat.csr_matrix((z['Y_data'], z['Y_indices'], z['Y_indptr']), shape=(T, n))
+    dtype = z['W0'].dtype
+    model = make_model(z['W0'], z['H0'], z['Th0'], z['lag_set'])
+    lib = session.lib_for(dtype)
+    pyY = PyMatrix(Y, dtype)
+    iters = int(z['max_iter'])
+    with capture_fds() as cap:
+        lib.c_trmf_train(byref(pyY), model.lag_set.ctypes.data_as(POINTER(c_uint32)), len(model.lag_set), byref(model.pyW),
+                         byref(model.pyH), byref(model.pylag_val), 0, float(z['lambdaI']), float(z['lambdaAR']), float(z['lambdaLag']),
+                         iters, 1, 1, 2, 1, 1, 1)
+    assert np.array_equal(model.W, z['W0']) and np.array_equal(model.H, z['H0']) and np.array_equal(model.lag_val, z['Th0'])
+    got = {'F': np.full(iters, -1.0), 'X': np.full(iters, -1.0), 'LV': np.full(iters, -1.0)}
+    for line in cap.err:
+        m = re.match(r'>> iter (\d+) (F|X|LV) (\S+)$', line.strip())
+        if m:
+            got[m.group(2)][int(m.group(1)) - 1] = float(m.group(3))
+    tol = 2e-5 if dtype == np.float64 else 2e-4
+    for key, ref in (('F', z['normF']), ('X', z['normX']), ('LV', z['normLV'])):
+        assert np.all((ref < 0) == (got[key] < 0)), (key, got[key], ref)
+        assert np.allclose(got[key], ref, rtol=tol), (key, got[key], ref)
 
 
 def test_rank_one_quirk_q2_is_reproduced(capfd):
