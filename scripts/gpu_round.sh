@@ -1,31 +1,24 @@
 #!/bin/bash
-# One gpurun call: GPU test suite, kernel-trace stats of bench.py (config 3), PMC passes of the F-solve kernel,
-# WRITE_SIZE calibration.  usage: scripts/gpu_round.sh <tag> [tests|notests]
-TAG=${1:-r02}; MODE=${2:-tests}
+# One gpurun call that reproduces a round's evidence (round 3 flow).  usage: scripts/gpu_round.sh <tag> [tests|notests]
+#   GPU test suite; bench c3 (with the CPU baseline) + kernel-trace stats; PMC of the F-solve kernels at c3 (fp32) and c5 (fp64)
+#   -> profiles/fsolve_traffic.json via scripts/make_traffic_json.py; PMC of the CG tile kernel; bench c5 + trace; a rank's compute
+#   share under the peer-less communicator; the host-side UBSan run (after `make -C exp-trmf-nips16_amd asan SAN=undefined`).
+TAG=${1:-r03}; MODE=${2:-tests}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
+export HSA_ENABLE_IPC_MODE_LEGACY=0
 if [ "$MODE" = tests ]; then
-  timeout 2400 python -m pytest tests -m gpu -x -q -s > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log
-  tail -5 $O/pytest.log
+  timeout 3000 python -m pytest tests -m gpu -x -q -s > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log; tail -3 $O/pytest.log
+  grep "FUZZ-MARGIN" $O/pytest.log | sed 's/.*FUZZ-MARGIN/FUZZ-MARGIN/' > $O/fuzz_margins.txt
 fi
 python bench.py --steps 20 --warmup 5 > $O/bench_c3.json 2> $O/bench_c3.err; tail -c 600 $O/bench_c3.json
-cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o c3 -- python $R/bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/trace.log 2>&1
-python $R/scripts/stats_table.py $O/trace > $O/kernel_stats.txt 2>&1; head -30 $O/kernel_stats.txt
-bash $R/scripts/pmc_fsolve.sh $TAG/pmc > $O/pmc_fsolve.txt 2>&1; tail -45 $O/pmc_fsolve.txt
-bash $R/scripts/pmc_kernel.sh $TAG/pmc_gramx "gram_x_kernel" > $O/pmc_gram_x.txt 2>&1; tail -22 $O/pmc_gram_x.txt
-bash $R/scripts/pmc_kernel.sh $TAG/pmc_hv "hv_tile_kernel" > $O/pmc_hv_tile.txt 2>&1; tail -22 $O/pmc_hv_tile.txt
-for C in WRITE_SIZE FETCH_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $O/wcal_$C -o w -- $R/scripts/ubench/write_calib > $O/wcal_$C.log 2>&1
-done
-python - <<PY > $O/write_calib.txt 2>&1
-import csv, glob, collections
-for C in ('WRITE_SIZE', 'FETCH_SIZE'):
-    agg = collections.defaultdict(list)
-    for f in glob.glob('$O/wcal_%s/**/*counter_collection.csv' % C, recursive=True):
-        for row in csv.DictReader(open(f)):
-            agg[row['Kernel_Name']].append(float(row['Counter_Value']))
-    for k, v in sorted(agg.items()):
-        print('%-12s %-40s mean %.1f (n=%d)  [19200000 bytes written = 18750 KB]' % (C, k[:40], sum(v) / len(v), len(v)))
-PY
-cat $O/write_calib.txt
+LINES_OUT=16 bash scripts/trace_config.sh $TAG/c3 c3 > $O/trace_c3.txt 2>&1; cut -c1-165 $O/trace_c3.txt
+bash scripts/pmc_fsolve.sh $TAG/pmc_c3 c3 > $O/pmc_fsolve_c3.txt 2>&1; tail -36 $O/pmc_fsolve_c3.txt
+bash scripts/pmc_kernel.sh $TAG/pmc_hv "hv_tile_kernel" > $O/pmc_hv_tile.txt 2>&1; tail -24 $O/pmc_hv_tile.txt
+python bench.py --config c5 --steps 6 --warmup 2 --no-cpu-baseline > $O/bench_c5.json 2> $O/bench_c5.err; tail -c 700 $O/bench_c5.json
+LINES_OUT=16 bash scripts/trace_config.sh $TAG/c5 c5 --steps 6 --warmup 2 > $O/trace_c5.txt 2>&1; cut -c1-165 $O/trace_c5.txt
+bash scripts/pmc_fsolve.sh $TAG/pmc_c5 c5 > $O/pmc_fsolve_c5.txt 2>&1; tail -36 $O/pmc_fsolve_c5.txt
+timeout 900 python scripts/shard_compute_times.py c3 1,2,4,8 replicate,timeshard > $O/shard_compute_times.txt 2>&1; grep "^c3" $O/shard_compute_times.txt
+bash scripts/hv_ablation.sh $TAG/abl 2>/dev/null | tee $O/hv_ablation.txt
+[ -f exp-trmf-nips16_amd/build/asan/trmf_float32.so ] && bash scripts/asan_gpu.sh $O/ubsan.log && tail -3 $O/ubsan.log
+scripts/ubench/f64_pipe > $O/f64_pipe.txt 2>&1; scripts/ubench/gridsync > $O/gridsync.txt 2>&1
