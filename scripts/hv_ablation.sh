@@ -1,7 +1,7 @@
 #!/bin/bash
 # Where does a CG launch spend its time?  bench.py with the fp32 library rebuilt under -DTRMF_HV_ABL=1 (Gram loads replaced by
 # constants), =2 (AR phases off), =3 (both): the per-launch times of hv_tile_kernel against the production build.
-# (Results are wrong by construction; only kernel durations are read.)  usage inside gpurun: scripts/hv_ablation.sh <outdir>
+# (Results are wrong by construction; only kernel durations are read.)  Build the variants first: make -C exp-trmf-nips16_amd abl  usage inside gpurun: scripts/hv_ablation.sh <outdir>
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$1; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for A in 0 1 2 3; do
