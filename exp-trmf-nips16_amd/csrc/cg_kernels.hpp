@@ -732,6 +732,39 @@ __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restr
     }
 }
 
+// Peer-to-peer exchange of the time-sharded UNFUSED CG: its kernels keep their partial sums in arrays and do not export edges,
+// so one small kernel pushes what the peers need after each operator application -- this rank's entries of up to four
+// partial-sum arrays into every peer's copy of the arrays (message 1 of the arena), its first / last midx rows of up to three
+// vectors into the edge message of the neighbour that stages them (messages 0 and 2 alternately: a peer may still be unpacking
+// the previous exchange's edges when this rank, one operator application further, pushes the next) -- and xchg_sync_kernel
+// follows (flags, halo rows).
+struct PushList { int n; int slot[4], begin[4], count[4]; };
+__global__ __launch_bounds__(256) void uts_push_kernel(const PeerTable *__restrict__ pt, int mi, const XState *__restrict__ st, int it,
+                                                       TileShard sh, int pstride, PushList pl, int edgeN, int KP, int nvec,
+                                                       const real *__restrict__ v0, const real *__restrict__ v1, const real *__restrict__ v2) {
+    if (it >= 0 && st->stop_it <= it) return;           // the application left nothing (the CG stopped at or before it): on every rank alike
+    const int gtid = blockIdx.x * 256 + threadIdx.x, gsize = gridDim.x * 256;
+    const double *mine = pt->msg[1][sh.rank];
+    for (int a = 0; a < pl.n; a++) {
+        const size_t base = (size_t)pl.slot[a] * pstride + pl.begin[a];
+        for (int i = gtid; i < pl.count[a]; i += gsize) {
+            const double v = mine[base + i];
+            for (int r = 0; r < sh.world; r++)
+                if (r != sh.rank) pt->msg[1][r][base + i] = v;
+        }
+    }
+    const real *src[kEdgeVecs] = {v0, v1, v2};
+    for (int side = 0; side < 2 && edgeN > 0; side++) {
+        const int nb = side == 0 ? sh.rank - 1 : sh.rank + 1;          // the first rows are the lower neighbour's upper halo, the last rows the upper neighbour's
+        if (nb < 0 || nb >= sh.world) continue;
+        real *edges = edge_base(pt->msg[mi][nb], sh, sh.rank);
+        const size_t row0 = side == 0 ? (size_t)sh.row_b * KP : (size_t)sh.row_e * KP - edgeN;
+        for (int v = 0; v < nvec; v++)
+            for (int e = gtid; e < edgeN; e += gsize) edges[((size_t)side * kEdgeVecs + v) * edgeN + e] = src[v][row0 + e];
+    }
+    __threadfence_system();
+}
+
 template <int MODE, int KQ, bool SHARD>
 __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,

@@ -153,7 +153,7 @@ struct TrmfSessionImpl {
         }
         for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2, ts0, ts1}) if (ev) (void)hipEventDestroy(ev);
         release_p2p();
-        for (hipEvent_t ev : {ov_a, ov_b}) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : {ov_b, ov_c[0], ov_c[1], ov_c[2], ov_c[3]}) if (ev) (void)hipEventDestroy(ev);
         if (side) (void)hipStreamDestroy(side);
         if (stream) (void)hipStreamDestroy(stream);
     }
@@ -161,7 +161,7 @@ struct TrmfSessionImpl {
         for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
         p2p.peer.clear();
         if (p2p.arena) (void)hipFree(p2p.arena);
-        p2p.arena = nullptr; p2p.on = false;
+        p2p.arena = nullptr; p2p.on = false; pbase_override = nullptr;
     }
     // One arena per rank: [message 0 | message 1 | message 2 | flag words: 3 messages x world source ranks x 64 bytes].
     // Collective: every rank allocates, exports its handle, gathers the handles (through the communicator) and opens the
@@ -212,7 +212,10 @@ struct TrmfSessionImpl {
         return 0;
     }
 
-    double *P(int slot) { return partials.p + (size_t)slot * xp.pstride; }
+    // base of the partial-sum arrays: the session's own buffer, or -- peer-to-peer time-sharded unfused CG -- message 1 of the arena
+    double *pbase_override = nullptr;
+    double *pbase() { return pbase_override ? pbase_override : partials.p; }
+    double *P(int slot) { return pbase() + (size_t)slot * xp.pstride; }
 
     // ---------------------------------------------------------------------------------------------
     // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).  The ABI's rows x k
@@ -450,7 +453,7 @@ struct TrmfSessionImpl {
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
         xp.full = full ? 1 : 0; xp.gstride = full ? 0 : (size_t)k * k; xp.trYTY = trYTY;
 
-        fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1); fmid.clear();
+        fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1); fcut.clear();
         if (!dense) {
             partition_by_nnz<uint64_t>((uint64_t)n, host_col_ptr.data(), comm->world, fbounds.data());
             partition_by_nnz<uint64_t>((uint64_t)T, host_row_ptr.data(), comm->world, xbounds.data());
@@ -758,18 +761,22 @@ struct TrmfSessionImpl {
     }
     int fs_mode = kShardMeasure, fs_calls = 0;
     hipEvent_t fs0 = nullptr, fs1 = nullptr, fs2 = nullptr;
-    // Overlapped all-gather of H (large item factors: config 5's is 512 MB): the rank's rows are solved in two launches of
-    // equal nnz; the first halves of every rank's block are gathered on a side stream while the second launch runs, the
-    // second halves follow on the solver stream, which then waits for the side stream.  Below kOverlapBytes per rank the
-    // second launch's tail costs more than the gather it hides (config 4).  TRMF_FOVERLAP=1|0 forces it on / off.
+    // Overlapped all-gather of H (large item factors: config 5's is 512 MB): the rank's rows are solved in C launches of
+    // equal nnz; chunk c of every rank's block is gathered on a side stream while launch c + 1 runs, the last chunk follows on
+    // the solver stream, which then waits for the side stream -- only the last chunk's gather is exposed.  C = 2..4 by size
+    // (one chunk per 16 MB of the rank's block); below kOverlapBytes per rank the extra launches' tails cost more than the
+    // gather they hide (config 4).  TRMF_FOVERLAP=0 switches it off, =2..4 forces that many chunks at any size.
     static constexpr uint64_t kOverlapBytes = 16ull << 20;
+    static constexpr int kMaxChunks = 4;
     hipStream_t side = nullptr;
-    hipEvent_t ov_a = nullptr, ov_b = nullptr;
-    std::vector<uint64_t> fmid;               // per rank: the row that splits its block's nnz in two
-    bool overlap_h(uint32_t rows) {
-        if (comm->world <= 1 || full || host_col_ptr.empty()) return false;
-        if (const char *e = getenv("TRMF_FOVERLAP")) return e[0] == '1';
-        return (uint64_t)rows * KP * sizeof(real) >= kOverlapBytes;
+    hipEvent_t ov_b = nullptr, ov_c[kMaxChunks] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint64_t> fcut;               // (world x (chunks + 1)) rows: chunk c of rank r = [fcut[r*(C+1)+c], fcut[r*(C+1)+c+1])
+    int fchunks = 0;
+    int overlap_chunks(uint32_t rows) {
+        if (comm->world <= 1 || full || host_col_ptr.empty()) return 0;
+        if (const char *e = getenv("TRMF_FOVERLAP")) { const int c = atoi(e); return c <= 0 ? 0 : std::max(2, std::min(kMaxChunks, c)); }
+        const uint64_t bytes = (uint64_t)rows * KP * sizeof(real);
+        return bytes >= kOverlapBytes ? (int)std::max<uint64_t>(2, std::min<uint64_t>(kMaxChunks, bytes / kOverlapBytes)) : 0;
     }
     int fsolve(PhaseEvents &ev) {
         // the SECOND call is the measured one: the first carries one-time costs on both sides of the comparison (code
@@ -782,37 +789,46 @@ struct TrmfSessionImpl {
         const bool replicate = fs_mode == kShardOff, measure = fs_mode == kShardMeasure && fs_calls == 1;
         const uint32_t rb = replicate ? 0u : (uint32_t)fbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)n : (uint32_t)fbounds[comm->rank + 1];
-        if (fs_mode == kShardOn && overlap_h(re - rb)) {
+        const int C = fs_mode == kShardOn ? overlap_chunks(re - rb) : 0;
+        if (C >= 2) {
             const int W_ = comm->world;
             if (!side) {
                 TRMF_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-                TRMF_HIP_CHECK(hipEventCreateWithFlags(&ov_a, hipEventDisableTiming));
                 TRMF_HIP_CHECK(hipEventCreateWithFlags(&ov_b, hipEventDisableTiming));
+                for (hipEvent_t &e : ov_c) TRMF_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             }
-            if ((int)fmid.size() != W_) {
-                fmid.resize(W_);
+            if (fchunks != C || fcut.size() != (size_t)W_ * (C + 1)) {
+                fchunks = C; fcut.resize((size_t)W_ * (C + 1));
                 for (int r = 0; r < W_; r++) {
-                    const uint64_t half = (host_col_ptr[fbounds[r]] + host_col_ptr[fbounds[r + 1]]) / 2;
-                    fmid[r] = (uint64_t)(std::lower_bound(host_col_ptr.begin() + fbounds[r], host_col_ptr.begin() + fbounds[r + 1], half) -
-                                         host_col_ptr.begin());
+                    const uint64_t n0 = host_col_ptr[fbounds[r]], n1 = host_col_ptr[fbounds[r + 1]];
+                    fcut[(size_t)r * (C + 1)] = fbounds[r]; fcut[(size_t)r * (C + 1) + C] = fbounds[r + 1];
+                    for (int c = 1; c < C; c++)
+                        fcut[(size_t)r * (C + 1) + c] = (uint64_t)(std::lower_bound(host_col_ptr.begin() + fbounds[r], host_col_ptr.begin() + fbounds[r + 1],
+                                                                                   n0 + (n1 - n0) * c / C) - host_col_ptr.begin());
                 }
             }
-            const uint32_t rm = (uint32_t)fmid[comm->rank];
             const uint64_t rowbytes = (uint64_t)KP * sizeof(real);
-            std::vector<uint64_t> b1(W_), e1(W_), b2(W_), e2(W_);
-            for (int r = 0; r < W_; r++) { b1[r] = fbounds[r] * rowbytes; e1[r] = fmid[r] * rowbytes; b2[r] = e1[r]; e2[r] = fbounds[r + 1] * rowbytes; }
+            const uint64_t *mine = fcut.data() + (size_t)comm->rank * (C + 1);
             TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
-            if (launch_fsolve_rows(rb, rm)) return kFail;
-            TRMF_HIP_CHECK(hipEventRecord(ov_a, stream));
-            if (launch_fsolve_rows(rm, re)) return kFail;
+            for (int c = 0; c < C; c++) {
+                if (launch_fsolve_rows((uint32_t)mine[c], (uint32_t)mine[c + 1])) return kFail;
+                if (c + 1 < C) TRMF_HIP_CHECK(hipEventRecord(ov_c[c], stream));
+            }
             TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
             TRMF_HIP_CHECK(hipGetLastError());
             fs_calls++;
-            TRMF_HIP_CHECK(hipStreamWaitEvent(side, ov_a, 0));
-            if (comm->allgatherv_ranges(H.p, b1.data(), e1.data(), side)) return kFail;      // first halves, under the second launch
-            TRMF_HIP_CHECK(hipEventRecord(ov_b, side));
-            if (comm->allgatherv_ranges(H.p, b2.data(), e2.data(), stream)) return kFail;    // second halves
-            TRMF_HIP_CHECK(hipStreamWaitEvent(stream, ov_b, 0));
+            std::vector<uint64_t> gb(W_), ge(W_);
+            for (int c = 0; c < C; c++) {                      // chunk c: on the side stream under launch c + 1; the last one on the solver stream
+                for (int r = 0; r < W_; r++) { gb[r] = fcut[(size_t)r * (C + 1) + c] * rowbytes; ge[r] = fcut[(size_t)r * (C + 1) + c + 1] * rowbytes; }
+                if (c + 1 < C) {
+                    TRMF_HIP_CHECK(hipStreamWaitEvent(side, ov_c[c], 0));
+                    if (comm->allgatherv_ranges(H.p, gb.data(), ge.data(), side)) return kFail;
+                } else {
+                    TRMF_HIP_CHECK(hipEventRecord(ov_b, side));
+                    if (comm->allgatherv_ranges(H.p, gb.data(), ge.data(), stream)) return kFail;
+                    TRMF_HIP_CHECK(hipStreamWaitEvent(stream, ov_b, 0));
+                }
+            }
             return 0;
         }
         if (measure) TRMF_HIP_CHECK(hipEventRecord(fs0, stream));
@@ -1128,6 +1144,8 @@ struct TrmfSessionImpl {
     TileShard ush{};                          // rank / world / rows / edge-slot geometry (no records: the unfused kernels keep arrays)
     std::vector<uint64_t> ubounds;            // AR-tile-aligned timestamp partition
     DevBuf<double> umsg;                      // edge message: world slots of 2 sides x 3 vectors x midx rows
+    double *umsg_ptr = nullptr;               // = umsg.p (communicator transport)
+    unsigned u_exchanges = 0;                 // peer to peer: exchanges issued so far (selects the edge message, 0 or 2)
     int u_tile0 = 0, u_ntiles = 0, u_tpr = 0, wn_slots = 1;
     int decide_cg_shard() {
         cg_shard = false; uts = false;
@@ -1150,6 +1168,12 @@ struct TrmfSessionImpl {
             ush.edge_off_dbl = 0; ush.slot_dbl = (unsigned)((edge_bytes + 15) / 16 * 2);
             wn_slots = std::max(1, std::min(nbe, kMaxPartials / W_));
             if (umsg.alloc((size_t)W_ * std::max(1u, ush.slot_dbl))) return kFail;
+            umsg_ptr = umsg.p;
+            if (e && e[0] == 'p') {        // peer to peer: the edge message and the partial-sum arrays live in the IPC-exported arena
+                release_p2p();
+                if (setup_p2p(std::max((size_t)W_ * ush.slot_dbl, (size_t)P_NSLOTS * xp.pstride))) return kFail;
+                pbase_override = xm[1]; u_exchanges = 0;
+            }
             return 0;
         }
         const double N = W_, sz = sizeof(real);
@@ -1162,11 +1186,27 @@ struct TrmfSessionImpl {
     // one grouped exchange of the time-sharded unfused CG: edge rows of nvec vectors + this rank's slots of partial arrays
     // (kind 0: apply_kernel's slots, 1: ar_tile_kernel's, 2: wnew_kernel's)
     struct PartialRef { int slot, kind; };
-    int uts_exchange(int nvec, real *v0, real *v1, real *v2, std::initializer_list<PartialRef> arrays) {
+    int uts_exchange(int it, int nvec, real *v0, real *v1, real *v2, std::initializer_list<PartialRef> arrays) {
         const int W_ = comm->world, edgeN = midx * KP;
         const bool edges = nvec > 0 && edgeN > 0;
+        if (p2p.on) {
+            PushList pl{};
+            const int tiles = (T + ar_TI - 1) / ar_TI, groups = KP / kArCols;
+            for (const PartialRef &a : arrays) {
+                const int b = a.kind == 0 ? comm->rank * apply_slots : a.kind == 1 ? u_tile0 * groups : comm->rank * wn_slots;
+                const int c = a.kind == 0 ? apply_slots : a.kind == 1 ? (std::min(tiles, u_tile0 + u_ntiles) - u_tile0) * groups : wn_slots;
+                pl.slot[pl.n] = a.slot; pl.begin[pl.n] = b; pl.count[pl.n] = c; pl.n++;
+            }
+            const int mi = (u_exchanges++ & 1) ? 2 : 0;      // edge messages alternate (identical count on every rank: all enqueue alike)
+            hipLaunchKernelGGL(uts_push_kernel, dim3(8), dim3(256), 0, stream, peer_table.p, mi, xstate.p, it, ush, xp.pstride, pl, edgeN, KP,
+                               edges ? nvec : 0, v0, v1, v2);
+            hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, mi, ++p2p.epoch[mi], xstate.p, it, ush, edgeN, KP,
+                               edges ? nvec : 0, v0, v1, v2);
+            TRMF_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         if (edges)
-            hipLaunchKernelGGL(edge_pack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, umsg.p, ush, edgeN, KP,
+            hipLaunchKernelGGL(edge_pack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, umsg_ptr, ush, edgeN, KP,
                                nvec, v0, v1, v2);
         std::vector<uint64_t> off[3];
         for (int kind = 0; kind < 3; kind++) {
@@ -1179,13 +1219,13 @@ struct TrmfSessionImpl {
             }
         }
         if (comm->group_begin()) return kFail;
-        int rc = edges ? comm->allgather_slots(umsg.p, (size_t)ush.slot_dbl * sizeof(double), stream) : 0;
+        int rc = edges ? comm->allgather_slots(umsg_ptr, (size_t)ush.slot_dbl * sizeof(double), stream) : 0;
         for (const PartialRef &a : arrays)
             if (rc == 0) rc = comm->allgatherv(P(a.slot), off[a.kind].data(), stream);
         if (comm->group_end()) return kFail;
         if (rc) return rc;
         if (edges)
-            hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, umsg.p, ush, edgeN,
+            hipLaunchKernelGGL(halo_unpack_kernel, dim3(std::max(1, std::min(8, (edgeN + 255) / 256))), dim3(256), 0, stream, umsg_ptr, ush, edgeN,
                                KP, nvec, v0, v1, v2);
         return 0;
     }
@@ -1197,7 +1237,7 @@ struct TrmfSessionImpl {
     //               direction av.d_out / residual av.r_out, apply_kernel multiplies it)
     int hv(const ArVecs &av, int cg_it, int last, int minus_b, real *out, int dot_mode) {
         XState *st = xstate.p;
-        double *Pb = partials.p;
+        double *Pb = pbase();
         const dim3 ar_grid(uts ? u_ntiles : (T + ar_TI - 1) / ar_TI, KP / kArCols);
         const int ar_tile0 = uts ? u_tile0 : 0;
         const size_t ar_lds = ar_tile_lds_bytes(ar_TI, midx, nlag);
@@ -1233,10 +1273,10 @@ struct TrmfSessionImpl {
                                comm->rank * apply_slots);
             TRMF_HIP_CHECK(hipGetLastError());
             const int c0 = P_CG0 + 3 * (cg_it & 1);
-            if (cg_it >= 1) return uts_exchange(3, av.d_out, av.r_out, out, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
-            if (cg_it == 0) return uts_exchange(1, out, nullptr, nullptr, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
-            if (minus_b) return uts_exchange(1, out, nullptr, nullptr, {{P_DOT, 0}, {P_LQ, 0}, {P_AR, 1}, {P_VV, 1}});   // gradient
-            return uts_exchange(0, nullptr, nullptr, nullptr, {{P_DOT, 0}});                                              // H s
+            if (cg_it >= 1) return uts_exchange(cg_it, 3, av.d_out, av.r_out, out, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
+            if (cg_it == 0) return uts_exchange(0, 1, out, nullptr, nullptr, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
+            if (minus_b) return uts_exchange(-1, 1, out, nullptr, nullptr, {{P_DOT, 0}, {P_LQ, 0}, {P_AR, 1}, {P_VV, 1}});   // gradient
+            return uts_exchange(-1, 0, nullptr, nullptr, nullptr, {{P_DOT, 0}});                                              // H s
         }
         if (!cg_shard) {
             hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
@@ -1267,7 +1307,7 @@ struct TrmfSessionImpl {
 
     int xsolve(XState *log_x = nullptr, double *log_n = nullptr) {   // log_*: record written by the accept kernel
         XState *st = xstate.p;
-        double *Pb = partials.p;
+        double *Pb = pbase();
         const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
         const bool fused = tile_TI > 0 && maxcg <= kCgHistCap;
         bool shard = false, timed = false;
@@ -1309,12 +1349,13 @@ struct TrmfSessionImpl {
         av = ArVecs{};
         av.v = dbuf[0]; av.r_in = rbuf[0];
         if (hv(av, 0, 0, 0, hbuf[0], 1)) return kFail;                   // H d0 and its three dot products
-        int upto = uts ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
+        const bool follow_u = uts && !p2p.on;                            // peer to peer: everything is enqueued at once, as on one GPU
+        int upto = follow_u ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
         for (int it = 1; it <= maxcg; it++) {                            // launch `maxcg` only closes the last iteration
             av.v = dbuf[(it - 1) & 1]; av.r_in = rbuf[(it - 1) & 1]; av.hd_in = hbuf[(it - 1) & 1];
             av.s = s.p; av.d_out = dbuf[it & 1]; av.r_out = rbuf[it & 1];
             if (hv(av, it, it == maxcg ? 1 : 0, 0, hbuf[it & 1], 1)) return kFail;
-            if (!uts) continue;
+            if (!follow_u) continue;
             if (it == upto && it < maxcg) {                              // time-sharded: follow the stop (identical on every rank)
                 int stop = kCgRunning;
                 TRMF_HIP_CHECK(hipMemcpyAsync(&stop, &xstate.p->stop_it, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -1325,7 +1366,7 @@ struct TrmfSessionImpl {
         }
         hipLaunchKernelGGL(wnew_kernel, dim3(nbw), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1], w_new.p, Pb, own_b, own_e,
                            uts ? comm->rank * wn_slots : 0);
-        if (uts && uts_exchange(1, s.p, nullptr, nullptr, {{P_GS, 2}, {P_SR, 2}, {P_SS, 2}})) return kFail;
+        if (uts && uts_exchange(-1, 1, s.p, nullptr, nullptr, {{P_GS, 2}, {P_SR, 2}, {P_SS, 2}})) return kFail;
         av = ArVecs{};
         av.v = s.p;
         if (hv(av, -1, 0, 0, hbuf[0], 1)) return kFail;                  // H s, <s,Hs>
@@ -1477,7 +1518,7 @@ struct TrmfSessionImpl {
             av.v = W.p;
             hipLaunchKernelGGL((ar_tile_kernel<AR_PLAIN>), dim3((T + ar_TI - 1) / ar_TI, KP / kArCols), dim3(kArThreads),
                                ar_tile_lds_bytes(ar_TI, midx, nlag), stream, xp, st, av, 0, 0, 0, lag_set.p, lag_steps.p, nsteps,
-                               theta.p, arbase.p, partials.p, ar_TI, 0);
+                               theta.p, arbase.p, pbase(), ar_TI, 0);
         }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_AR), nbar, &st->gs);
         const double ar = host_double(&st->gs);

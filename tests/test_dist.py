@@ -87,12 +87,12 @@ def test_time_sharded_cg_matches_single_process(world, shape, mode):
     'p2p': the peer-to-peer form of the exchange -- every rank's kernels write their tile records and edge rows straight
     into the other ranks' IPC-mapped message buffers and synchronise through flag words (bounded waits); here the "peers"
     are processes sharing the one GPU, the code path (IPC handles, remote stores, system-scope flags) is the multi-GPU one.
-    'overlap': the all-gather of H split in two (ranges per rank) behind the two halves of the F-solve, forced on at these sizes."""
+    'overlap': the all-gather of H in 2 / 4 chunks (a byte range per rank each) behind the next chunk of the F-solve, forced on at these sizes."""
     import dist_worker
     iters = 5 if mode == 'measure' else 3
     env = {} if mode == 'measure' else {'TRMF_CG': mode}
     if mode == 'overlap':       # the F-solve in two launches, the first halves of H gathered on a side stream under the second
-        env = {'TRMF_FOVERLAP': '1', 'TRMF_FSHARD': 'shard', 'TRMF_CG': 'timeshard'}
+        env = {'TRMF_FOVERLAP': '4' if world == 3 else '2', 'TRMF_FSHARD': 'shard', 'TRMF_CG': 'timeshard'}     # chunks
     out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, shape, env))
     p, m0 = dist_worker._problem(shape)
     for dtype in (np.float32, np.float64):
@@ -172,16 +172,19 @@ def test_two_ranks_one_gpu_config4_shape_replicated_cg():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('world', [2, 4])
-def test_time_sharded_unfused_cg(world, monkeypatch):
+@pytest.mark.parametrize('world,transport', [(2, 'comm'), (4, 'comm'), (2, 'p2p'), (4, 'p2p')])
+def test_time_sharded_unfused_cg(world, transport, monkeypatch):
     """The UNFUSED CG (long lag sets; forced here with TRMF_NO_HV_TILE) sharded over time: every kernel of the solve runs on the
     rank's own block of AR tiles, per step the ranks exchange midx edge rows of d, r, H d and their slots of the partial-sum
     arrays -- nothing T-sized.  All ranks bit-identical to each other; equal to the single-process unfused run up to the
-    grouping of the partial sums (fp64 1e-9, fp32 1e-3), same CG counts."""
+    grouping of the partial sums (fp64 1e-9, fp32 1e-3), same CG counts.  'p2p': the exchange peer to peer (the partial-sum
+    arrays and two alternating edge messages in the IPC-exported arena, pushed by a small kernel after each application)."""
     import dist_worker
     from trmf import session, synth
     iters = 3
     env = {'TRMF_NO_HV_TILE': '1'}
+    if transport == 'p2p':
+        env['TRMF_CG'] = 'p2p'
     out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c4', env))
     p, m0 = dist_worker._problem('c4')
     monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
