@@ -50,7 +50,7 @@ struct XParams {
     // timestamp (gstride == 0) and fun = base + 0.5*(tr Y^T Y + sum_i w_i^T G w_i - 2 b_i.w_i)
     int full;
     int pstride;                       // entries between the partial-sum arrays (>= kMaxPartials, >= tile count)
-    size_t gstride;                    // elements between consecutive per-timestamp Grams (k*k or 0)
+    size_t gstride;                    // elements between consecutive per-timestamp Grams (k*k, packed_gram_elems(k), or 0)
     double trYTY;
 };
 
@@ -423,7 +423,28 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
 // otherwise.  The AR + ridge part comes in as `base` (ar_tile_kernel); this kernel adds the cached-Gram product.
 // One thread per (row, column); `rpb` rows per block; the row's v is staged in LDS.
 // dot_mode 0: <out,out>   1: <v,out>
-__global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__restrict__ st, int cg_it,
+//
+// PACKED (unfused path, per-timestamp Grams): G_i is symmetric and this product is its only reader, so gram_x_kernel keeps
+// the upper triangle only -- element (s, t), s <= t, at s k - s (s - 1) / 2 + (t - s), packed_gram_elems(k) per
+// timestamp -- and the stream of a CG step is halved (config 5: 1.64 -> 0.83 GB).  The rpb packed triangles of a row
+// group are contiguous: the workgroup copies them to LDS with coalesced 16-byte loads, requested one group ahead (they
+// are in flight under the previous group's products), and thread (row, t) reads column t above the diagonal and row t
+// beyond it, in the same order s = 0 .. k-1 as the full form: the results are bit-identical.
+__host__ __device__ inline size_t packed_gram_elems(int k) { return (((size_t)k * (k + 1) / 2) + 1) & ~(size_t)1; }
+#ifndef TRMF_APPLY_ABL
+#define TRMF_APPLY_ABL 0              // scripts/ubench/apply_packed.hip: 1 = no products, 2 = no LDS copy either
+#endif
+// STAGES = 16-byte loads per thread and row group >= rpb * packed_gram_elems(k) / 512 (17 at k = 64), a template
+// parameter because the loads and the LDS copy must be straight-line code: with a (uniform) branch per load the
+// compiler waits for each load before issuing the next (measured: 10.9 us per row group, 296 us per launch at config 5,
+// slower than the full form).  Loads past the group are clamped to the last pair of G; the LDS buffer is STAGES * 512 reals.
+__host__ __device__ inline int apply_stages(int k) {
+    const size_t need = ((size_t)(256 / k) * packed_gram_elems(k) + 511) / 512;
+    return need <= 5 ? 5 : need <= 10 ? 10 : 17;
+}
+
+template <bool PACKED, int STAGES = 1>
+__global__ __launch_bounds__(256, 2) void apply_kernel(XParams p, const XState *__restrict__ st, int cg_it,
                                                     const real *__restrict__ v, const real *__restrict__ rvec,
                                                     const real *__restrict__ base,
                                                     const real *__restrict__ G,
@@ -440,7 +461,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     const bool cg = cg_it >= 0;
     if (cg && st->stop_it <= cg_it) return;
     const int k = p.k, KP = p.KP;
-    const bool shared_gram = p.gstride == 0;          // full-observation path: one H^T H for every timestamp
+    const bool shared_gram = !PACKED && p.gstride == 0;          // full-observation path: one H^T H for every timestamp
     real *Gs = reinterpret_cast<real *>(apply_smem);
     if (shared_gram) {
         for (int e = threadIdx.x; e < k * k; e += 256) Gs[e] = G[e];
@@ -453,20 +474,66 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
     // rows [row0, row0 + nrows): all of them, or this rank's block when the Gram product is sharded across GPUs
     // (the partial sums then land in this rank's slot range [slot0, slot0 + gridDim.x) and are all-gathered)
     const int ngroups = (nrows + rpb - 1) / rpb;
+    typedef real Pair __attribute__((ext_vector_type(2)));
+    Pair stage[STAGES];
+    const int Lp = (int)p.gstride;                                  // PACKED: elements per timestamp (even)
+    // no predicate on the loads: the tail of a short last group re-reads the final pair of G
+    const size_t lastpair = (size_t)p.T * (size_t)Lp - 2;
+#define TRMF_APPLY_REQUEST(GRP)                                                                                   \
+    {                                                                                                             \
+        const size_t first = (size_t)(row0 + (GRP) * rpb) * (size_t)Lp + 2 * threadIdx.x;                         \
+        _Pragma("unroll") for (int j = 0; j < STAGES; j++)                                                        \
+            stage[j] = *reinterpret_cast<const Pair *>(G + min(first + 512 * j, lastpair));                       \
+    }
+    if constexpr (PACKED)
+        if ((int)blockIdx.x < ngroups) TRMF_APPLY_REQUEST((int)blockIdx.x)
     for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
         const int i = row0 + grp * rpb + lr;
         const bool active = active_lane && grp * rpb + lr < nrows;
-        real x = 0;
-        if (active) x = v[(size_t)i * KP + tp];
+        // every per-row operand is requested here, ahead of the next group's Grams: loads retire in order, a wait for one
+        // of these issued after TRMF_APPLY_REQUEST would wait for the whole group
+        real x = 0, o = 0, rv = 0, bv = 0;
+        if (active) {
+            x = v[(size_t)i * KP + tp];
+            o = base[(size_t)i * KP + tp];                         // lambdaI*v + lambdaAR*AR'(v), ar_tile_kernel
+            if (cg) rv = rvec[(size_t)i * KP + tp];
+            if (minus_b) bv = Bv[(size_t)i * KP + t];
+        }
         __syncthreads();
         vs[threadIdx.x] = x;
+        if constexpr (PACKED) {
+#pragma unroll
+            for (int j = 0; j < STAGES; j++) {
+                if (TRMF_APPLY_ABL == 2) { asm volatile("" ::"v"(stage[j])); continue; }
+                *reinterpret_cast<Pair *>(Gs + 2 * threadIdx.x + 512 * j) = stage[j];
+            }
+        }
         __syncthreads();
+        if constexpr (PACKED)
+            if (grp + (int)gridDim.x < ngroups) TRMF_APPLY_REQUEST(grp + (int)gridDim.x)
         if (active) {
-            real o = base[(size_t)i * KP + tp];                    // lambdaI*v + lambdaAR*AR'(v), ar_tile_kernel
             // cached Gram: sum_s G_i[s][t] * v_i[s]
             const real *vi = vs + lr * k;
             double acc = 0;
-            if (shared_gram) {
+            if constexpr (PACKED) {
+                const real *U = Gs + lr * Lp;
+                int up = t;                                         // (s, t) for s <= t: s k - s (s - 1) / 2 + t - s
+                const int across = t * k - t * (t - 1) / 2 - t;     // (t, s) for s > t: this + s
+                if (TRMF_APPLY_ABL) acc = (double)U[t];
+                for (int s0 = 0; s0 < (TRMF_APPLY_ABL ? 0 : k); s0 += 8) {   // eight LDS reads in flight, then their products in order
+                    real u[8], w[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const int sc = min(s0 + j, k - 1);
+                        u[j] = U[sc <= t ? up : across + sc];
+                        w[j] = vi[sc];
+                        up += k - 1 - sc;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (s0 + j < k) acc += (double)u[j] * (double)w[j];
+                }
+            } else if (shared_gram) {
 #pragma unroll 8
                 for (int s = 0; s < k; s++) acc += (double)Gs[s * k + t] * (double)vi[s];
             } else {
@@ -475,7 +542,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
                 for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k] * (double)vi[s];
             }
             if (minus_b) {
-                const double bb = (double)Bv[(size_t)i * KP + t];
+                const double bb = (double)bv;
                 lq += (double)x * (acc - 2.0 * bb);                          // w.(Gw) - 2 b.w
                 acc -= bb;
             }
@@ -483,7 +550,7 @@ __global__ __launch_bounds__(256) void apply_kernel(XParams p, const XState *__r
             out[(size_t)i * KP + tp] = o;
             dot += (double)(dot_mode ? x : o) * (double)o;
             if (cg) {
-                rhd += (double)rvec[(size_t)i * KP + tp] * (double)o;        // <r,Hd>
+                rhd += (double)rv * (double)o;                               // <r,Hd>
                 hh += (double)o * (double)o;                                 // <Hd,Hd>
             }
         }

@@ -1050,17 +1050,18 @@ __global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const
 // ---- X-side Gram cache: one wavefront per timestamp row --------------------------------------------
 // G_i = sum_{j in Omega_i} h_j h_j^T (k x k, full symmetric, row-major) and b_i = sum_j y_ij h_j, straight
 // from the accumulator registers: diagonal tiles hold both triangles, an off-diagonal tile is written
-// twice (as is and mirrored).  No LDS, no workgroup barrier: a timestamp has ~nnz/T entries (1000 at
+// twice (as is and mirrored).  PACKED (the unfused X-solve, whose product is the only reader): the upper triangle
+// only, row s at s k - s (s - 1) / 2, `gs` elements per timestamp.  No LDS, no workgroup barrier: a timestamp has ~nnz/T entries (1000 at
 // config 3), so one wavefront amortises the ring's two-iteration lead 60x instead of 15x, and the four
 // wavefronts of a workgroup never wait for each other.
-template <int NT, bool RHS_PAD>
+template <int NT, bool RHS_PAD, bool PACKED>
 __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ idx,
                                                      const real *__restrict__ val,
                                                      const real *__restrict__ Hf,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
-                                                     uint32_t zero_row) {
+                                                     uint32_t zero_row, size_t gs) {
     constexpr int KP = kTile * NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
             if (g == 0) Bv[(size_t)row * KP + kTile * q + c] = (kTile * q + c < k) ? v : real(0);
         }
     }
-    real *Grow = G + (size_t)row * k * k;
+    real *Grow = G + (size_t)row * gs;
     int t = 0;
 #pragma unroll
     for (int ti = 0; ti < NT; ti++)
@@ -1111,8 +1112,12 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
                 const int rw = kTile * ti + Mfma16<real>::row(lane, r), cl = kTile * tj + c;
                 if (rw < k && cl < k) {
                     const real a = st.acc[t][r];
-                    Grow[rw * k + cl] = a;
-                    if (ti != tj) Grow[cl * k + rw] = a;
+                    if constexpr (PACKED) {
+                        if (rw <= cl) Grow[rw * k - rw * (rw - 1) / 2 + cl - rw] = a;
+                    } else {
+                        Grow[rw * k + cl] = a;
+                        if (ti != tj) Grow[cl * k + rw] = a;
+                    }
                 }
             }
 }

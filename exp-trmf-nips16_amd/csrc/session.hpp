@@ -118,6 +118,7 @@ struct TrmfSessionImpl {
     std::vector<PhaseEvents> events;
     static constexpr int kEventRing = 64;
     int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
+    bool gpacked = false;                     // unfused path: G holds upper triangles (packed_gram_elems(k) per timestamp), apply_kernel<true>
     int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), tiles of the problem
     // fused path: per-tile records of each launch (cg_kernels.hpp "per-tile partial records") in three message buffers:
     // CG launches of even / odd iteration, gradient + plain launch.  tsh: the one-rank view (one slot, every tile);
@@ -376,7 +377,7 @@ struct TrmfSessionImpl {
     int alloc_time_scratch() {
         const size_t NV = (size_t)T * KP;
         if (full && dense && gemm_part.alloc((size_t)kGemmChunks * (size_t)std::max(T, n) * KP)) return kFail;
-        if (G.alloc((full ? 1 : (size_t)T * k * k) + kHvGramPad) || Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
+        if (Bv.alloc(NV) || g.alloc(NV) || s.alloc(NV) || r.alloc(NV) ||
             d0.alloc(NV) || d1.alloc(NV) || Hd.alloc(NV) || r1.alloc(NV) || Hd1.alloc(NV) || w_new.alloc(NV) ||
             lossrow.alloc(T))
             return kFail;
@@ -413,6 +414,18 @@ struct TrmfSessionImpl {
                 tile_TI = TI;
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
+        }
+        // The cached Grams: k x k per timestamp for the fused kernel; the unfused path's product streams them once per CG
+        // step and nothing else (1.64 GB per step at config 5), so there only the upper triangle is kept (packed_gram_elems)
+        gpacked = !full && tile_TI == 0 && !getenv("TRMF_GRAM_FULL");
+        const size_t gelems = gpacked ? packed_gram_elems(k) : (size_t)k * k;
+        if (G.alloc((full ? 1 : (size_t)T * gelems) + kHvGramPad)) return kFail;
+        if (gpacked) {
+            const size_t need = (size_t)apply_stages(k) * 512 * sizeof(real);
+            if (allow_dyn_lds(apply_kernel<true, 5>, need, "packed cached-Gram product") ||
+                allow_dyn_lds(apply_kernel<true, 10>, need, "packed cached-Gram product") ||
+                allow_dyn_lds(apply_kernel<true, 17>, need, "packed cached-Gram product"))
+                return kFail;
         }
         if (setup_tile_messages()) return kFail;
         {   // unfused path: timestamps per AR tile.  One workgroup per CU (LDS); a tile costs ~(TI + 2 midx) staged rows,
@@ -451,7 +464,7 @@ struct TrmfSessionImpl {
         if (partials.alloc((size_t)P_NSLOTS * xp.pstride)) return kFail;
         xp.T = T; xp.k = k; xp.KP = KP; xp.NT = NT; xp.nlag = nlag; xp.midx = midx;
         xp.lambdaI = lambdaI; xp.lambdaAR = lambdaAR; xp.eps_cg = eps_cg;
-        xp.full = full ? 1 : 0; xp.gstride = full ? 0 : (size_t)k * k; xp.trYTY = trYTY;
+        xp.full = full ? 1 : 0; xp.gstride = full ? 0 : gelems; xp.trYTY = trYTY;
 
         fbounds.resize(comm->world + 1); xbounds.resize(comm->world + 1); fcut.clear();
         if (!dense) {
@@ -848,12 +861,15 @@ struct TrmfSessionImpl {
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
         if (re <= rb) return;
         const dim3 grid((re - rb + 3) / 4), block(256);
-        if (rhs_pad_ok<NT_>(k))       // rhs accumulated by the MFMAs in the panel's pad columns
-            hipLaunchKernelGGL((gram_x_kernel<NT_, true>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p,
-                               Bv.p, rb, re, k, (uint32_t)n);
-        else
-            hipLaunchKernelGGL((gram_x_kernel<NT_, false>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p,
-                               Bv.p, rb, re, k, (uint32_t)n);
+#define TRMF_LAUNCH_GRAM_X(PAD, PACKED)                                                                                      \
+    hipLaunchKernelGGL((gram_x_kernel<NT_, PAD, PACKED>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p, Bv.p, \
+                       rb, re, k, (uint32_t)n, xp.gstride)
+        if (rhs_pad_ok<NT_>(k)) {     // rhs accumulated by the MFMAs in the panel's pad columns
+            if (gpacked) TRMF_LAUNCH_GRAM_X(true, true); else TRMF_LAUNCH_GRAM_X(true, false);
+        } else {
+            if (gpacked) TRMF_LAUNCH_GRAM_X(false, true); else TRMF_LAUNCH_GRAM_X(false, false);
+        }
+#undef TRMF_LAUNCH_GRAM_X
     }
     template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
         if (re > rb)
@@ -889,7 +905,7 @@ struct TrmfSessionImpl {
         if (replicate) return 0;                                    // every rank built every row: nothing to gather
         if (cg_shard) return 0;                                     // sharded Gram product: a rank only ever reads its own G / b rows
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx1, stream));
-        if (gather_rows(G.p, xbounds, (size_t)k * k * sizeof(real))) return kFail;
+        if (gather_rows(G.p, xbounds, xp.gstride * sizeof(real))) return kFail;
         if (gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx2, stream));
         return 0;
@@ -1177,7 +1193,7 @@ struct TrmfSessionImpl {
             return 0;
         }
         const double N = W_, sz = sizeof(real);
-        const double t_saved = (double)T * k * k * sz * (1.0 - 1.0 / N) / 4e12;
+        const double t_saved = (double)T * (double)xp.gstride * sz * (1.0 - 1.0 / N) / 4e12;
         const double t_gather = 40e-6 + (double)T * KP * sz * (1.0 - 1.0 / N) / ((N - 1.0) * 50e9);
         cg_shard = t_saved > 2.0 * t_gather;
         if (e && (e[0] == 's' || e[0] == 'r')) cg_shard = (e[0] == 's');
@@ -1251,7 +1267,23 @@ struct TrmfSessionImpl {
         if (last) return 0;                                              // the closing launch has no product
         const real *operand = cg_it >= 1 ? av.d_out : av.v;
         const real *resid = cg_it >= 1 ? av.r_out : av.r_in;
-        const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : 0;        // shared Gram staged per workgroup
+        // shared Gram, or the packed Grams of one row group, staged per workgroup
+        const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : gpacked ? (size_t)apply_stages(k) * 512 * sizeof(real) : 0;
+        auto launch_apply = [&](int blocks, int row_b, int rows, int slot_b) {
+#define TRMF_LAUNCH_APPLY_PACKED(NS)                                                                                          \
+    hipLaunchKernelGGL((apply_kernel<true, NS>), dim3(blocks), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p, \
+                       Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, row_b, rows, slot_b)
+            if (gpacked) {
+                switch (apply_stages(k)) {
+                    case 5: TRMF_LAUNCH_APPLY_PACKED(5); break;
+                    case 10: TRMF_LAUNCH_APPLY_PACKED(10); break;
+                    default: TRMF_LAUNCH_APPLY_PACKED(17); break;
+                }
+            } else
+#undef TRMF_LAUNCH_APPLY_PACKED
+                hipLaunchKernelGGL(apply_kernel<false>, dim3(blocks), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
+                                   Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, row_b, rows, slot_b);
+        };
         if (full && !getenv("TRMF_NO_APPLY_SHARED")) {       // one Gram for every timestamp: the product runs on the matrix pipe (never sharded)
 #define TRMF_LAUNCH_APPLY_SHARED(NTV)                                                                                           \
     hipLaunchKernelGGL((apply_shared_mfma_kernel<NTV>), dim3(nba), dim3(256), apply_shared_lds_bytes(KP), stream, xp, st, cg_it,  \
@@ -1268,9 +1300,7 @@ struct TrmfSessionImpl {
         if (uts) {
             // this rank's timestamps only; then one grouped exchange: the edge rows the next kernel stages as halo and the
             // rank's slots of the partial sums
-            hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
-                               Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, ush.row_b, ush.row_e - ush.row_b,
-                               comm->rank * apply_slots);
+            launch_apply(apply_slots, ush.row_b, ush.row_e - ush.row_b, comm->rank * apply_slots);
             TRMF_HIP_CHECK(hipGetLastError());
             const int c0 = P_CG0 + 3 * (cg_it & 1);
             if (cg_it >= 1) return uts_exchange(cg_it, 3, av.d_out, av.r_out, out, {{c0, 0}, {c0 + 1, 0}, {c0 + 2, 0}});
@@ -1279,16 +1309,13 @@ struct TrmfSessionImpl {
             return uts_exchange(-1, 0, nullptr, nullptr, nullptr, {{P_DOT, 0}});                                              // H s
         }
         if (!cg_shard) {
-            hipLaunchKernelGGL(apply_kernel, dim3(nba), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
-                               Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, 0, T, 0);
+            launch_apply(nba, 0, T, 0);
             return 0;
         }
         // Gram product on this rank's timestamps only; its rows of `out` and its slots of the partial sums are
         // all-gathered (one grouped round), so every rank continues with identical vectors and scalars
         const int rb = (int)xbounds[comm->rank], re = (int)xbounds[comm->rank + 1];
-        hipLaunchKernelGGL(apply_kernel, dim3(apply_slots), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
-                           Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, rb, re - rb,
-                           comm->rank * apply_slots);
+        launch_apply(apply_slots, rb, re - rb, comm->rank * apply_slots);
         TRMF_HIP_CHECK(hipGetLastError());
         std::vector<uint64_t> poff(comm->world + 1);
         for (int r = 0; r <= comm->world; r++) poff[r] = (uint64_t)r * apply_slots * sizeof(double);
