@@ -34,6 +34,7 @@ struct XState {
     double rho_hist[kCgHistCap + 2];
     int stop_it, r_parity;
     int p2p_error;                // a peer-to-peer exchange of the time-sharded CG timed out (sticky; reported by sync())
+    long long p2p_diag[4];        // the first timeout: message index, launch (it), peer, expected epoch, flag value seen
 };
 constexpr int kCgRunning = 0x7fffffff;
 
@@ -780,7 +781,13 @@ __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restr
         const unsigned long long *mine = pt->flags[mi][sh.rank] + (size_t)tid * kFlagStride;
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-            if (wall_clock64() - t0 > kP2pTimeoutTicks) { failed = 1; break; }
+            if (wall_clock64() - t0 > kP2pTimeoutTicks) {
+                if (!atomicExch(&failed, 1)) {
+                    st->p2p_diag[0] = mi * 1000000ll + (long long)(it + 1) * 1000 + tid; st->p2p_diag[1] = (long long)epoch;
+                    st->p2p_diag[2] = (long long)__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
     }

@@ -1053,6 +1053,15 @@ struct TrmfSessionImpl {
     // one exchange of message `mi` after a launch (`it`: the CG launch index, -1 for the gradient / plain launch) and the
     // unpacking of the neighbours' edge rows of nvec vectors: through the communicator (in-place all-gather of the slots +
     // halo_unpack_kernel) or peer to peer (the launch wrote into the peers' arenas; xchg_sync_kernel raises / awaits the flags)
+    // Peer to peer, before the first launch of a solve that writes into the peers' messages: wait until every peer has
+    // finished the previous solve.  Inside a solve a rank is never more than one exchange ahead of a peer and consecutive
+    // exchanges use different records / arrays; across the solve boundary nothing else orders the ranks once the F-solve
+    // is replicated (no all-gather between two X-solves), and the gradient launch of the next solve would overwrite sums
+    // the slower rank's acceptance test has yet to read (seen as ranks disagreeing on |g| and on the CG's stop: timeouts).
+    void p2p_fence(const TileShard &sh) {
+        hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, 1, ++p2p.epoch[1], xstate.p, -1, sh, 0, KP, 0,
+                           (real *)nullptr, (real *)nullptr, (real *)nullptr);
+    }
     int exchange(int mi, int it, int nvec, real *v0, real *v1, real *v2) {
         const int edgeN = midx * KP;
         if (p2p.on) {
@@ -1351,6 +1360,7 @@ struct TrmfSessionImpl {
         } else {
             if (gram_x(shard)) return kFail;                                   // G, b
         }
+        if (p2p.on && (fused ? shard : uts)) p2p_fence(fused ? tsh_rank : ush);
         if (fused) {
             if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
             if (timed) {
@@ -1504,9 +1514,27 @@ struct TrmfSessionImpl {
     int sync() {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         if (p2p.on) {               // a bounded wait of the peer-to-peer exchange ran out: the factors are not to be trusted
-            int bad = 0;
-            TRMF_HIP_CHECK(hipMemcpy(&bad, &xstate.p->p2p_error, sizeof bad, hipMemcpyDeviceToHost));
-            if (bad) { set_error("time-sharded CG: a peer-to-peer exchange timed out (TRMF_CG=p2p)"); return kFail; }
+            XState hx;
+            TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));
+            if (hx.p2p_error) {
+                char msg[256];
+                snprintf(msg, sizeof msg, "time-sharded CG: a peer-to-peer exchange timed out (TRMF_CG=p2p): rank %d, message %lld, launch %lld, "
+                         "peer %lld: expected epoch %lld, flag %lld", comm->rank, hx.p2p_diag[0] / 1000000, hx.p2p_diag[0] / 1000 % 1000 - 1,
+                         hx.p2p_diag[0] % 1000, hx.p2p_diag[1], hx.p2p_diag[2]);
+                set_error(msg);
+                if (getenv("TRMF_P2P_DEBUG")) {       // what this rank derived its stop decisions from
+                    std::vector<double> hp((size_t)P_NSLOTS * xp.pstride);
+                    TRMF_HIP_CHECK(hipMemcpy(hp.data(), pbase(), hp.size() * sizeof(double), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[p2p debug] rank %d: %s\n  stop_it %d cg_iter %d rho %.17g %.17g %.17g gnorm %.17g cgtol %.9g\n", comm->rank, msg,
+                            hx.stop_it, hx.cg_iter, hx.rho_hist[0], hx.rho_hist[1], hx.rho_hist[2], hx.gnorm, (double)hx.cgtol);
+                    for (int a = 0; a < P_NSLOTS; a++) {
+                        double t = 0; int nz = 0;
+                        for (int q = 0; q < xp.pstride; q++) { t += hp[(size_t)a * xp.pstride + q]; nz += hp[(size_t)a * xp.pstride + q] != 0; }
+                        fprintf(stderr, "  partial array %2d: sum %.17g (%d nonzero)\n", a, t, nz);
+                    }
+                }
+                return kFail;
+            }
         }
         return 0;
     }

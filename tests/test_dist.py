@@ -27,7 +27,18 @@ def _spawn(fn, world, *args):
     procs = [ctx.Process(target=fn, args=(r, world, port, q) + args) for r in range(world)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=1500) for _ in range(1 if fn.__name__ == 'cpu_sharded_fsolve' else world)]
+    out, want, waited = [], (1 if fn.__name__ == 'cpu_sharded_fsolve' else world), 0
+    while len(out) < want:          # a rank that died will never report: fail at once instead of waiting out the timeout
+        try:
+            out.append(q.get(timeout=5))
+        except Exception:
+            waited += 5
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or waited > 1500:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                raise AssertionError('rank process exit codes {} after {} s'.format([p.exitcode for p in procs], waited))
     for p in procs:
         p.join(timeout=300)
         assert p.exitcode == 0
