@@ -928,27 +928,6 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             st->stop_it = stopped ? 0 : kCgRunning; st->r_parity = 0;
         }
     }
-    if (nlag > 0) {
-        auto put = [&](int e, real th) {
-            const int tt = e / nlag, l = e - tt * nlag;
-            thp[l * KP + colpos(tt, NT_T)] = th;
-            thd[l * KP + tt] = p.lambdaAR * (double)th;
-        };
-#pragma unroll
-        for (int m = 0; m < kHvThetaRegs; m++)
-            if (tid + 256 * m < nTh) put(tid + 256 * m, thr[m]);
-#pragma nounroll
-        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) put(e, theta[e]);
-#pragma nounroll
-        for (int e = tid; e < nlag * (KP - k); e += 256) {                  // pad columns: exact zeros
-            const int l = e / (KP - k), tt = k + (e - l * (KP - k));
-            thp[l * KP + colpos(tt, NT_T)] = 0;
-            thd[l * KP + tt] = 0;
-        }
-        if (tid < nlag) lags[tid] = lagr;
-#pragma nounroll
-        for (int e = tid + 256; e < nlag; e += 256) lags[e] = (int)lag_set[e];
-    }
     // ---- requests, in consumption order (vmcnt retires in order) ----
     // (a) operand rows: the staged rows [i0-midx, i0+TI+midx) are one contiguous range of the vector,
     //     stage element e = vector element (i0-midx)*KP + e.  Buffer descriptors do the clipping: an
@@ -1001,6 +980,37 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         g_soff += (j + 1 < k) ? rowbytes : 0;               // j >= k: a finite duplicate, multiplied by a zero pad
     }
     __builtin_amdgcn_sched_barrier(0);                      // keep the requests above everything that follows
+    if (MODE == HV_CG_STEP && early) {
+        // the partials become visible to the compiler only here: it otherwise starts their sum right behind their loads
+        // (`v_add_f64 x, 0` in the loading block) and the wait for them lands in front of every request above
+#pragma unroll
+        for (int m = 0; m < kEarlyPartials; m++)
+#pragma unroll
+            for (int a3 = 0; a3 < 3; a3++) asm volatile("" : "+v"(pq[a3][m]));
+    }
+    // Theta / lag set -> LDS only now: the staging has loops, and with it above the requests the compiler drained every
+    // outstanding load (s_waitcnt vmcnt(0)) before issuing the first operand load -- one memory round trip per launch
+    if (nlag > 0) {
+        auto put = [&](int e, real th) {
+            const int tt = e / nlag, l = e - tt * nlag;
+            thp[l * KP + colpos(tt, NT_T)] = th;
+            thd[l * KP + tt] = p.lambdaAR * (double)th;
+        };
+#pragma unroll
+        for (int m = 0; m < kHvThetaRegs; m++)
+            if (tid + 256 * m < nTh) put(tid + 256 * m, thr[m]);
+#pragma nounroll
+        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) put(e, theta[e]);
+#pragma nounroll
+        for (int e = tid; e < nlag * (KP - k); e += 256) {                  // pad columns: exact zeros
+            const int l = e / (KP - k), tt = k + (e - l * (KP - k));
+            thp[l * KP + colpos(tt, NT_T)] = 0;
+            thd[l * KP + tt] = 0;
+        }
+        if (tid < nlag) lags[tid] = lagr;
+#pragma nounroll
+        for (int e = tid + 256; e < nlag; e += 256) lags[e] = (int)lag_set[e];
+    }
 
     if (MODE == HV_CG_STEP) {
         double dHd = 0, rHd = 0, HH = 0;
