@@ -151,6 +151,29 @@ def test_fused_cg_equals_unfused_on_multiwave_grids(dtype, k, T, nlag, monkeypat
         assert relfro(fused.W, plain.W) < tol['factor'] and relfro(fused.H, plain.H) < tol['factor']
 
 
+@pytest.mark.parametrize('dtype,k,nlag', [(np.float64, 64, 8), (np.float32, 40, 16), (np.float64, 21, 5), (np.float32, 7, 3), (np.float64, 2, 2)])
+def test_packed_grams_equal_full_grams_on_the_unfused_path(dtype, k, nlag, monkeypatch):
+    """Unfused X-solve: the cached Grams are kept as packed upper triangles and apply_kernel<true, STAGES> stages them
+    through LDS (all three STAGES instantiations are hit: k = 64 -> 17, 40 -> 10, 21 / 7 / 2 -> 5, with row groups that
+    straddle wavefronts and a short last group).  Same values multiplied in the same order as with full k x k Grams
+    (TRMF_GRAM_FULL): the factors must be bit-identical."""
+    p = synth.sparse_problem(n=60, T=1237, k=k, nlag=nlag, density=0.05, dtype=dtype, seed=29)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], k, seed=29)
+    monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
+
+    def run():
+        model = make_model(m0.W, m0.H, m0.lag_val, p['lag_set'])
+        with session.Session(p['Y'], model, missing=True, **synth.HYPER) as s:
+            s.run(3); st = s.stats(3); s.download()
+        return model, [x['cg_iter'] for x in st]
+
+    packed, cg_p = run()
+    monkeypatch.setenv('TRMF_GRAM_FULL', '1')
+    full, cg_f = run()
+    assert cg_p == cg_f
+    assert np.array_equal(packed.W, full.W) and np.array_equal(packed.H, full.H) and np.array_equal(packed.lag_val, full.lag_val)
+
+
 PAPER_LAGS = list(range(1, 25)) + list(range(7 * 24, 8 * 24))          # run_electricity.py:13, run_traffic.py:13
 
 
