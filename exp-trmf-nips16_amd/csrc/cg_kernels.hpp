@@ -242,6 +242,13 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
         return b;
     };
     Batch cur = request(0);
+    // CG step: this thread's entries of the three dot-product arrays, requested with the first batch -- the Theta staging
+    // below drains every outstanding load (loop + LDS store), so anything requested after it costs a second round trip
+    double pre[3] = {0, 0, 0};
+    if (STEP && tid < np) {
+        const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
+        pre[0] = Pp[tid]; pre[1] = Pp[(size_t)p.pstride + tid]; pre[2] = Pp[2 * (size_t)p.pstride + tid];
+    }
     for (int e = tid; e < nlag * kArCols; e += kArThreads) {
         const int l = e / kArCols, cc = e - l * kArCols, t = collog(c0 + cc, p.NT);
         ths[e] = t < p.k ? theta[(size_t)t * nlag + l] : real(0);
@@ -250,8 +257,8 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
     bool stopped = false;
     if (STEP) {
         const double *Pp = Pbase + (size_t)(P_CG0 + 3 * ((it - 1) & 1)) * p.pstride;
-        double dHd = 0, rHd = 0, HH = 0;
-        for (int i = tid; i < np; i += kArThreads) { dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i]; }
+        double dHd = pre[0], rHd = pre[1], HH = pre[2];
+        for (int i = tid + kArThreads; i < np; i += kArThreads) { dHd += Pp[i]; rHd += Pp[(size_t)p.pstride + i]; HH += Pp[2 * (size_t)p.pstride + i]; }
         block_allsum3_wide(dHd, rHd, HH, smem);
         const double rho_prev_d = st->rho_hist[it - 1];
         const real rho_prev = (real)rho_prev_d;
