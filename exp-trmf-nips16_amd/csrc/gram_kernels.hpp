@@ -188,7 +188,11 @@ __device__ __forceinline__ void load_factor_slice(R (&dst)[NT], __amdgpu_buffer_
     }
 }
 
-template <int NT, int D, bool DO_MMA, bool WITH_LOSS, bool RHS_PAD = false, typename Next, typename RowDone>
+// TAIL (single-row streams with estride == 4 only: group u of an iteration is entries e0 + 4u .. e0 + 4u + 3): the last
+// iteration of the row runs after the loop and issues the arithmetic of the groups that hold entries only.  The loop
+// body stays one basic block (a branch inside it costs the exact waits); behind the loop nothing
+// is in flight that a conservative wait could delay.  Skipped groups are all-zero operands: the sums are unchanged.
+template <int NT, int D, bool DO_MMA, bool WITH_LOSS, bool RHS_PAD = false, bool TAIL = false, typename Next, typename RowDone>
 __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__restrict__ idx,
                                           const real *__restrict__ val, const real *__restrict__ X,
                                           uint32_t zero_row, uint32_t estride, int lane,
@@ -233,36 +237,39 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     // iteration, in place: every load still has a full iteration of MFMA time (24 x 32 cycles) to land, and
     // there is no second operand set to copy into (12 + 4 register moves per iteration that the shared
     // f32 ALUs would have to execute, section 4.1 (3) of DESIGN.md).
-    while (d0.row >= 0) {
+    auto consume = [&](auto U, real ycons) {             // the arithmetic of group u of the iteration being consumed
+        constexpr int u = decltype(U)::value;
+        real xt[NT];                                     // operands of group u; the last slice carries y in its pads
+#pragma unroll
+        for (int q = 0; q < NT; q++) xt[q] = x[u][q];
+        if constexpr (RHS_PAD) xt[NT - 1] = quad_inject<u>(x[u][NT - 1], ycons);
+        else {
+#pragma unroll
+            for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
+        }
+        if (DO_MMA) {
+            int t = 0;
+#pragma unroll
+            for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+                for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(xt[ti], xt[tj], st.acc[t]);
+        }
+        if (WITH_LOSS) {
+            real d = 0;
+#pragma unroll
+            for (int q = 0; q < NT; q++) d = fma(wq[q], x[u][q], d);
+            d = row16_sum(d);
+            const real res = yx[u] - d;                   // trmf.cpp:238 (val_type arithmetic)
+            st.loss += (double)res * (double)res;         // masked lanes: y = 0, x = 0 -> 0
+        }
+    };
+    while (TAIL ? d1.row >= 0 : d0.row >= 0) {
         // ---- single basic block ----
         const real ycons = ysel;                         // y of the iteration being consumed (RHS_PAD)
         promote_entries();                               // entries of n+1 (loaded one iteration ago)
         load_entries(d2);                                // entries of n+2
         static_for<D>([&](auto U) {
-            constexpr int u = decltype(U)::value;
-            real xt[NT];                                 // operands of group u; the last slice carries y in its pads
-#pragma unroll
-            for (int q = 0; q < NT; q++) xt[q] = x[u][q];
-            if constexpr (RHS_PAD) xt[NT - 1] = quad_inject<u>(x[u][NT - 1], ycons);
-            else {
-#pragma unroll
-                for (int q = 0; q < NT; q++) st.b[q] = fma(yx[u], x[u][q], st.b[q]);
-            }
-            if (DO_MMA) {
-                int t = 0;
-#pragma unroll
-                for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-                    for (int tj = ti; tj < NT; tj++, t++) st.acc[t] = Mfma16<real>::mma(xt[ti], xt[tj], st.acc[t]);
-            }
-            if (WITH_LOSS) {
-                real d = 0;
-#pragma unroll
-                for (int q = 0; q < NT; q++) d = fma(wq[q], x[u][q], d);
-                d = row16_sum(d);
-                const real res = yx[u] - d;               // trmf.cpp:238 (val_type arithmetic)
-                st.loss += (double)res * (double)res;     // masked lanes: y = 0, x = 0 -> 0
-            }
+            consume(U, ycons);
             // pin the order "all of group u's arithmetic, then its reload": left alone, the scheduler moves the
             // reload above MFMAs that still read the slot, renames it and waits for the fresh load at once
             __builtin_amdgcn_sched_barrier(0);
@@ -272,6 +279,16 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
         // ---- between iterations ----
         if (d1.row != d0.row) { row_done(d0.row); }
         d0 = d1; d1 = d2; next(d2);
+    }
+    if constexpr (TAIL) {
+        if (d0.row >= 0) {                               // the row's last iteration: groups with entries only
+            const int ngr = (int)((d0.end - d0.e0 + 3u) >> 2);
+            const real ycons = ysel;
+            static_for<D>([&](auto U) {
+                if (decltype(U)::value < ngr) consume(U, ycons);
+            });
+            row_done(d0.row);
+        }
     }
 }
 
@@ -603,6 +620,9 @@ __device__ __forceinline__ void fmac4_row_bcast(double &acc, const Quad<double> 
         : "+v"(acc)
         : "v"(S.v[0]), "v"(S.v[1]), "v"(S.v[2]), "v"(S.v[3]), "v"(R.v[0]), "v"(R.v[1]), "v"(R.v[2]), "v"(R.v[3]), "n"(BC));
 }
+#ifndef TRMF_MFMA_TAIL
+#define TRMF_MFMA_TAIL 1       // the Gram's last iteration issues its non-empty groups only (gram_ring TAIL): config 5 rows have ~50 entries
+#endif
 #ifndef TRMF_TRAIL_MFMA
 #define TRMF_TRAIL_MFMA 1      // measured at config 5: 12.6-12.8 ms with the MFMA trailing update, 13.0 ms with the DPP-fused FMAs (7b)
 #endif
@@ -639,8 +659,8 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
         real nowq[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) nowq[q] = 0;
-        gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
-                                               SingleRowStream{4u * kRingDepth}, [](int) {});
+        gram_ring<NT, kRingDepth, true, false, false, TRMF_MFMA_TAIL != 0>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
+                                                                          SingleRowStream{4u * kRingDepth}, [](int) {});
     }
     // right-hand side: fold the 4 lane groups, then lane l = 16 q + c keeps b[l]
     real y = 0, dinv = 1;
