@@ -175,8 +175,8 @@ def cpu_baseline(config, iters, state_file, gpu_file=''):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'shard'],
