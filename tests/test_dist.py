@@ -183,7 +183,7 @@ def test_two_ranks_one_gpu_config4_shape_replicated_cg():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('world,transport', [(2, 'comm'), (4, 'comm'), (2, 'p2p'), (4, 'p2p')])
+@pytest.mark.parametrize('world,transport', [(2, 'comm'), (4, 'comm'), (2, 'p2p'), (4, 'p2p'), (2, 'replicate')])
 def test_time_sharded_unfused_cg(world, transport, monkeypatch):
     """The UNFUSED CG (long lag sets; forced here with TRMF_NO_HV_TILE) sharded over time: every kernel of the solve runs on the
     rank's own block of AR tiles, per step the ranks exchange midx edge rows of d, r, H d and their slots of the partial-sum
@@ -196,6 +196,8 @@ def test_time_sharded_unfused_cg(world, transport, monkeypatch):
     env = {'TRMF_NO_HV_TILE': '1'}
     if transport == 'p2p':
         env['TRMF_CG'] = 'p2p'
+    if transport == 'replicate':    # the CG on every rank, the X-side Gram build sharded: the packed Grams are all-gathered
+        env['TRMF_CG'] = 'replicate'; env['TRMF_GRAMX'] = 'shard'
     out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c4', env))
     p, m0 = dist_worker._problem('c4')
     monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
