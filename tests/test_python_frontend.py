@@ -148,11 +148,14 @@ def test_grid_search_on_gpu_matches_reference_harness(capsys):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('dtype,missing', [(np.float32, True), (np.float64, True), (np.float64, False)])
-def test_session_append_rows_equals_fresh_session(dtype, missing):
+@pytest.mark.parametrize('dtype,missing,unfused', [(np.float32, True, False), (np.float64, True, False), (np.float64, False, False),
+                                                   (np.float64, True, True), (np.float32, True, True)])
+def test_session_append_rows_equals_fresh_session(dtype, missing, unfused, monkeypatch):
     """trmf_session_append_rows: a session grown by a block of new timestamps (CSR appended, CSC rebuilt on the device,
     W rolled forward on the device) must continue exactly like a fresh session created on the whole matrix with the
-    host-side warm start."""
+    host-side warm start.  unfused: the two-kernel X-solve (TRMF_NO_HV_TILE), whose packed Gram cache is re-sized with T."""
+    if unfused:
+        monkeypatch.setenv('TRMF_NO_HV_TILE', '1')
     import scipy.sparse as smat
     from helpers import make_model
     from trmf import session, synth
