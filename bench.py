@@ -272,6 +272,7 @@ def main():
         elapsed = float(t.item())
 
     st = s.stats(args.steps)
+    described = s.describe()          # which phases are sharded / which CG form the measure-once rule chose (set-up iterations, untimed)
     bytes_f = s.fsolve_bytes()
     ms_fk = float(np.mean([x['ms_F_kernel'] for x in st]))
     s.download()
@@ -299,7 +300,12 @@ def main():
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
                 args.config, cfg['n'], cfg['T'], cfg.get('density', 1.0), nnz, cfg['k'], len(prob['lag_set']), dtype.name,
                 int(missing), hyper['lambdaI'], hyper['lambdaAR'], hyper['lambdaLag']),
-                'parallelism': 'item rows of the F-solve and timestamp rows of the X-side Gram build sharded x{} with RCCL all-gathers, each replicated instead when its all-gather costs more than it saves (decided once, from the timings of the second iteration); fused CG replicated or sharded over time (tile records + midx halo rows exchanged per launch), whichever the measured iterations 2-4 find faster (long-lag / large-T problems: cached-Gram product sharded, H d all-gathered per step)'.format(world)},
+                # chosen by the library's measure-once rules in set-up iterations BEFORE the warm-up (their effect on the factors is undone;
+                # DESIGN.md section 6): F rows / X-side Gram rows sharded or replicated, the CG replicated or sharded over time with the
+                # exchange through RCCL or peer to peer -- with the slowest rank's measured X phase of every candidate
+                'parallelism': described,
+                'phases_ms_rank0': {'F': float(np.mean([x['ms_F'] for x in st])), 'X': float(np.mean([x['ms_X'] for x in st])),
+                                    'Theta': float(np.mean([x['ms_LV'] for x in st]))}},
             'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_mfma_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,

@@ -775,9 +775,11 @@ struct PeerTable {                              // lives in device memory (index
 };
 constexpr int kFlagStride = 8;                  // 64 bytes between the flags of different source ranks
 constexpr long long kP2pTimeoutTicks = 1000000000;  // 10 s of the 100 MHz wall clock
+constexpr long long kP2pTrialTicks = 20000000;      // 200 ms: the trial exchange of the set-up (a failure there only means "use the communicator")
 __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restrict__ pt, int mi, unsigned long long epoch, XState *__restrict__ st, int it,
                                                         TileShard sh, int edgeN, int KP, int nvec,
-                                                        real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
+                                                        real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2,
+                                                        long long timeout_ticks) {
     if (it >= 0 && st->stop_it <= it) return;   // launch `it` left no message (the CG stopped at or before it): on every rank alike
     __shared__ int failed;
     const int tid = threadIdx.x;
@@ -788,7 +790,7 @@ __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restr
         const unsigned long long *mine = pt->flags[mi][sh.rank] + (size_t)tid * kFlagStride;
         const long long t0 = wall_clock64();
         while (__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-            if (wall_clock64() - t0 > kP2pTimeoutTicks) {
+            if (wall_clock64() - t0 > timeout_ticks) {
                 if (!atomicExch(&failed, 1)) {
                     st->p2p_diag[0] = mi * 1000000ll + (long long)(it + 1) * 1000 + tid; st->p2p_diag[1] = (long long)epoch;
                     st->p2p_diag[2] = (long long)__hip_atomic_load(mine, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -129,19 +129,28 @@ struct TrmfSessionImpl {
     // peer-to-peer exchange (TRMF_CG=p2p; cg_kernels.hpp "peer-to-peer form of the exchange"): messages + flag words of
     // this rank in one IPC-exported arena, the peers' arenas opened, the pointer table in device memory
     struct P2p {
-        bool on = false, uncached = false;
+        bool on = false;                      // arena allocated, exported, mapped by every peer, and the trial exchange passed on EVERY rank
         void *arena = nullptr;
         size_t bytes = 0;
         std::vector<void *> peer;             // opened arenas of the other ranks (own slot: nullptr)
         unsigned long long epoch[3] = {0, 0, 0};
+        double *msg[3] = {nullptr, nullptr, nullptr};   // this rank's three messages inside the arena
+        std::string note;                     // why the peer-to-peer transport is unavailable (empty: available or not tried)
     } p2p;
+    bool p2p_use = false;                     // transport of the CURRENT X-solve (select_transport)
     DevBuf<PeerTable> peer_table;
     std::vector<uint64_t> tbounds;            // tile-aligned timestamp partition of the time-sharded CG
     bool ts_possible = false;
-    enum { kTsOff = 0, kTsOn = 1, kTsMeasure = 2 };
-    int ts_mode = kTsMeasure, ts_calls = 0, cg_pred = 4;
-    bool ts_last = false;                     // the last X-solve ran time-sharded
-    float ts_ms[2] = {0, 0};                  // X phase, replicated / time-sharded (the measured calls)
+    // Form of the multi-GPU X-solve: the CG replicated on every rank, or sharded over time with the
+    // per-launch exchange through the communicator or peer to peer.  Forced by TRMF_CG, else measured once: every candidate
+    // runs two X phases (the second timed on every rank), the slowest rank's time decides.  The peer-to-peer transport is
+    // a candidate whenever its set-up (IPC arenas + a trial exchange with a short bound) succeeded on every rank.
+    enum { kXRep = 0, kXTsComm = 1, kXTsP2p = 2, kXForms = 3 };
+    int x_form = kXRep;                       // the decided form; -1 while the candidates are being measured
+    std::vector<int> x_cands;
+    int x_calls = 0, cg_pred = 4;
+    float x_ms[kXForms] = {0, 0, 0};          // X phase of the measured call of each candidate (this rank)
+    double x_ms_all[kXForms] = {0, 0, 0};     // ... the slowest rank's (after the decision)
     hipEvent_t ts0 = nullptr, ts1 = nullptr;
     int ar_TI = 64, nbar = 1;                 // unfused path: timestamps per ar_tile_kernel workgroup, its partial-sum slots
     DevBuf<real> arbase;                      // lambdaI*v + lambdaAR*AR'(v) between ar_tile_kernel and apply_kernel
@@ -162,41 +171,79 @@ struct TrmfSessionImpl {
         for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
         p2p.peer.clear();
         if (p2p.arena) (void)hipFree(p2p.arena);
-        p2p.arena = nullptr; p2p.on = false; pbase_override = nullptr;
+        p2p.arena = nullptr; p2p.on = false; p2p_use = false; pbase_override = nullptr;
+        for (int m = 0; m < 3; m++) p2p.msg[m] = nullptr;
+    }
+    // test hook TRMF_P2P_FAIL=<stage>[:rank] (stage: alloc | export | open | fence): the set-up fails there (on that rank only)
+    bool p2p_forced_failure(const char *stage) const {
+        const char *e = getenv("TRMF_P2P_FAIL");
+        if (!e) return false;
+        const std::string v(e);
+        const size_t c = v.find(':');
+        if (v.substr(0, c) != stage) return false;
+        return c == std::string::npos || atoi(v.c_str() + c + 1) == comm->rank;
     }
     // One arena per rank: [message 0 | message 1 | message 2 | flag words: 3 messages x world source ranks x 64 bytes].
-    // Collective: every rank allocates, exports its handle, gathers the handles (through the communicator) and opens the
-    // other ranks' arenas.  Explicitly requested (TRMF_CG=p2p), so every failure is reported instead of falling back.
-    int setup_p2p(size_t msg_doubles) {
-        const int W_ = comm->world;
-        if (W_ > kMaxPeers) { set_error("TRMF_CG=p2p supports at most 8 ranks"); return kFail; }
-        const size_t msg_bytes = (msg_doubles * sizeof(double) + 255) / 256 * 256, flag_bytes = (size_t)3 * W_ * kFlagStride * sizeof(unsigned long long);
-        p2p.bytes = 3 * msg_bytes + flag_bytes;
-        p2p.uncached = hipExtMallocWithFlags(&p2p.arena, p2p.bytes, hipDeviceMallocUncached) == hipSuccess;
-        if (!p2p.uncached) {
-            (void)hipGetLastError();
-            TRMF_HIP_CHECK(hipMalloc(&p2p.arena, p2p.bytes));
-        }
-        TRMF_HIP_CHECK(hipMemsetAsync(p2p.arena, 0, p2p.bytes, stream));
-        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        hipIpcMemHandle_t mine;
-        TRMF_HIP_CHECK(hipIpcGetMemHandle(&mine, p2p.arena));
+    // COLLECTIVE, and the outcome is an agreement: every rank allocates (uncached device memory: peers store into it while
+    // local kernels poll it -- without that allocation flavour there is NO peer-to-peer transport), exports its
+    // handle, the handles and an ok flag travel through the communicator, every rank maps the other arenas, the ok flags
+    // travel again, and one flags-only exchange with a SHORT bound (200 ms) runs as a trial.  If any step failed on any
+    // rank, every rank releases what it has and the session goes on with the communicator transport (p2p.note says why;
+    // one line on stderr under verbose or TRMF_P2P_VERBOSE).  `required` (TRMF_CG=p2p: explicitly requested) turns
+    // "unavailable" into an error instead.  Returns kFail only for that and for a failing communicator.
+    int setup_p2p(size_t msg_doubles, bool required) {
+        const int W_ = comm->world, me = comm->rank;
+        auto unavailable = [&](const std::string &why) -> int {          // taken by EVERY rank together
+            release_p2p();
+            p2p.note = why;
+            if (required) { set_error("TRMF_CG=p2p: " + why); return kFail; }
+            if (me == 0 && (verbose || getenv("TRMF_P2P_VERBOSE")))
+                fprintf(stderr, ">> peer-to-peer exchange unavailable (%s): the time-sharded CG uses the communicator\n", why.c_str());
+            return 0;
+        };
+        p2p.note.clear();
+        if (W_ > kMaxPeers) return unavailable("more than 8 ranks");
+        constexpr size_t kSlot = 128;                                     // [0..63] IPC handle, [64] ok flag
         static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle slot");
         DevBuf<unsigned char> slots;
-        if (slots.alloc((size_t)64 * W_)) return kFail;
-        TRMF_HIP_CHECK(hipMemcpyAsync(slots.p + (size_t)64 * comm->rank, &mine, sizeof mine, hipMemcpyHostToDevice, stream));
-        if (comm->allgather_slots(slots.p, 64, stream)) return kFail;
-        std::vector<unsigned char> all((size_t)64 * W_);
-        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        TRMF_HIP_CHECK(hipMemcpy(all.data(), slots.p, all.size(), hipMemcpyDeviceToHost));
+        if (slots.alloc(kSlot * W_)) return kFail;
+        std::vector<unsigned char> all(kSlot * W_);
+        auto agree = [&](const unsigned char *mine, int *who_failed) -> int {   // all-gather of one slot per rank; ok = byte 64
+            TRMF_HIP_CHECK(hipMemcpyAsync(slots.p + kSlot * me, mine, kSlot, hipMemcpyHostToDevice, stream));
+            if (comm->allgather_slots(slots.p, kSlot, stream)) return kFail;
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+            TRMF_HIP_CHECK(hipMemcpy(all.data(), slots.p, all.size(), hipMemcpyDeviceToHost));
+            *who_failed = -1;
+            for (int r = 0; r < W_; r++) if (!all[kSlot * r + 64]) { *who_failed = r; break; }
+            return 0;
+        };
+        // ---- stage 1: arena + handle ----
+        const size_t msg_bytes = (msg_doubles * sizeof(double) + 255) / 256 * 256, flag_bytes = (size_t)3 * W_ * kFlagStride * sizeof(unsigned long long);
+        p2p.bytes = 3 * msg_bytes + flag_bytes;
+        unsigned char mine[kSlot] = {0};
+        bool ok = !p2p_forced_failure("alloc") && hipExtMallocWithFlags(&p2p.arena, p2p.bytes, hipDeviceMallocUncached) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); p2p.arena = nullptr; }
+        if (ok) {
+            ok = hipMemsetAsync(p2p.arena, 0, p2p.bytes, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+            hipIpcMemHandle_t h;
+            ok = ok && !p2p_forced_failure("export") && hipIpcGetMemHandle(&h, p2p.arena) == hipSuccess;
+            if (ok) std::memcpy(mine, &h, sizeof h); else (void)hipGetLastError();
+        }
+        mine[64] = ok ? 1 : 0;
+        int bad = -1;
+        if (agree(mine, &bad)) return kFail;
+        if (bad >= 0) return unavailable("rank " + std::to_string(bad) + " could not allocate / export an uncached IPC arena");
+        const std::vector<unsigned char> handles = all;
+        // ---- stage 2: map the peers' arenas ----
         p2p.peer.assign(W_, nullptr);
         PeerTable tab{};
-        for (int r = 0; r < W_; r++) {
+        ok = !p2p_forced_failure("open");
+        for (int r = 0; r < W_ && ok; r++) {
             unsigned char *base = (unsigned char *)p2p.arena;
-            if (r != comm->rank) {
+            if (r != me) {
                 hipIpcMemHandle_t h;
-                std::memcpy(&h, all.data() + (size_t)64 * r, sizeof h);
-                TRMF_HIP_CHECK(hipIpcOpenMemHandle(&p2p.peer[r], h, hipIpcMemLazyEnablePeerAccess));
+                std::memcpy(&h, handles.data() + kSlot * r, sizeof h);
+                if (hipIpcOpenMemHandle(&p2p.peer[r], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); p2p.peer[r] = nullptr; ok = false; break; }
                 base = (unsigned char *)p2p.peer[r];
             }
             for (int m = 0; m < 3; m++) {
@@ -204,13 +251,33 @@ struct TrmfSessionImpl {
                 tab.flags[m][r] = reinterpret_cast<unsigned long long *>(base + 3 * msg_bytes) + (size_t)m * W_ * kFlagStride;
             }
         }
+        std::memset(mine, 0, sizeof mine); mine[64] = ok ? 1 : 0;
+        if (agree(mine, &bad)) return kFail;          // also: nobody starts writing into a peer before every rank has opened every arena
+        if (bad >= 0) return unavailable("rank " + std::to_string(bad) + " could not map a peer's arena");
         if (peer_table.upload(&tab, 1)) return kFail;
-        for (int m = 0; m < 3; m++) { xm[m] = tab.msg[m][comm->rank]; p2p.epoch[m] = 0; }
+        for (int m = 0; m < 3; m++) { p2p.msg[m] = tab.msg[m][me]; p2p.epoch[m] = 0; }
+        // ---- stage 3: a trial exchange (flags only) with a short bound ----
+        TileShard sh{}; sh.rank = me; sh.world = W_;
+        hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, 1, ++p2p.epoch[1], xstate.p, -1, sh, 0, KP, 0,
+                           (real *)nullptr, (real *)nullptr, (real *)nullptr, kP2pTrialTicks);
+        ok = hipGetLastError() == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
+        XState hx;
+        if (ok) { TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost)); ok = !hx.p2p_error; }
+        if (p2p_forced_failure("fence")) ok = false;
+        std::memset(mine, 0, sizeof mine); mine[64] = ok ? 1 : 0;
+        if (agree(mine, &bad)) return kFail;
+        if (bad >= 0) {
+            TRMF_HIP_CHECK(hipMemset(&xstate.p->p2p_error, 0, sizeof(int)));      // the trial's failure is not the session's
+            return unavailable("the trial flag exchange timed out on rank " + std::to_string(bad));
+        }
         p2p.on = true;
-        // nobody starts writing into a peer before every rank has opened every arena
-        if (comm->allgather_slots(slots.p, 64, stream)) return kFail;
-        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
+    }
+    // message buffers / partial-sum base of the transport the next X-solve uses
+    void select_transport(bool use_p2p) {
+        p2p_use = use_p2p && p2p.on;
+        for (int m = 0; m < 3; m++) xm[m] = p2p_use ? p2p.msg[m] : xmsg_own[m].p;
+        pbase_override = (p2p_use && uts) ? p2p.msg[1] : nullptr;
     }
 
     // base of the partial-sum arrays: the session's own buffer, or -- peer-to-peer time-sharded unfused CG -- message 1 of the arena
@@ -328,7 +395,7 @@ struct TrmfSessionImpl {
             for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
         for (hipEvent_t *ev : {&gx0, &gx1, &gx2, &fs0, &fs1, &fs2, &ts0, &ts1}) TRMF_HIP_CHECK(hipEventCreate(ev));
-        if (gramx_times.alloc((size_t)2 * comm->world)) return kFail;
+        if (gramx_times.alloc((size_t)4 * comm->world)) return kFail;
         if (comm->world == 1) { gramx_mode = kGramxShard; fs_mode = kShardOn; }     // nothing to decide
         if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
         if (const char *e = getenv("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
@@ -341,8 +408,10 @@ struct TrmfSessionImpl {
             if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         }
-        return 0;
+        created = true;
+        return autotune();
     }
+    bool created = false;        // create() has finished: append_rows() re-tunes, alloc_time_scratch() inside create() does not
 
     static double sum_squares(const real *v, uint64_t count) {
         double acc = 0;
@@ -476,7 +545,9 @@ struct TrmfSessionImpl {
                 xbounds[r] = (uint64_t)T * r / comm->world;
             }
         }
-        return decide_cg_shard();
+        if (decide_cg_shard()) return kFail;
+        init_x_forms();
+        return 0;
     }
 
     // Message buffers of the fused path and the tile partition of the time-sharded CG: rank r owns
@@ -509,16 +580,29 @@ struct TrmfSessionImpl {
             }
         }
         release_p2p();
-        const char *e = getenv("TRMF_CG");
-        if (e && e[0] == 't') ts_mode = kTsOn;                 // timeshard: exchange through the communicator
-        else if (e && e[0] == 'r') ts_mode = kTsOff;           // replicate
-        else if (e && e[0] == 'p') {                           // p2p: time-sharded, peer-to-peer exchange
-            ts_mode = kTsOn;
-            if (ts_possible) return setup_p2p(doubles);
-        }
         for (int m = 0; m < 3; m++) { if (xmsg_own[m].alloc(doubles)) return kFail; xm[m] = xmsg_own[m].p; }
+        // peer-to-peer arena: required under TRMF_CG=p2p, otherwise tried (and silently dropped where it does not work) so
+        // that the measure-once rule can consider it; never with TRMF_CG=timeshard|replicate or TRMF_NO_P2P
+        const char *e = getenv("TRMF_CG");
+        if (ts_possible && ((e && e[0] == 'p') || (!e && !getenv("TRMF_NO_P2P"))) && setup_p2p(doubles, e != nullptr)) return kFail;
         return 0;
     }
+    // candidates of the X-solve's form, called once the geometry (tiles, uts) and the peer-to-peer arena are settled
+    void init_x_forms() {
+        x_cands.clear(); x_calls = 0; x_form = kXRep;
+        for (int f = 0; f < kXForms; f++) { x_ms[f] = 0; x_ms_all[f] = 0; }
+        const char *e = getenv("TRMF_CG");
+        const bool fused_ts = tile_TI > 0 && ts_possible;
+        if (!fused_ts && !uts) return;                                   // one rank, or nothing time-sharded: no choice
+        if (e && e[0] == 'p') { x_form = kXTsP2p; return; }              // set-up succeeded, or create() has failed already
+        if (e && e[0] == 't') { x_form = kXTsComm; return; }
+        if (fused_ts && e && e[0] == 'r') { x_form = kXRep; return; }
+        if (fused_ts) x_cands.push_back(kXRep);
+        x_cands.push_back(kXTsComm);
+        if (p2p.on) x_cands.push_back(kXTsP2p);
+        x_form = x_cands.size() == 1 ? x_cands[0] : -1;
+    }
+    static const char *x_form_name(int f) { return f == kXRep ? "replicated" : f == kXTsComm ? "time-sharded (communicator)" : f == kXTsP2p ? "time-sharded (peer to peer)" : "measuring"; }
 
     // ---- per-series affine transform of a resident dense Y (trmf_session_set_series_transform) -------------------------
     // rolling_validate(transform=True) -- the paper scripts' setting -- refits a NormalizedTransform on every growing
@@ -648,7 +732,7 @@ struct TrmfSessionImpl {
         if (gramx_mode != kGramxReplicate && comm->world > 1 && !getenv("TRMF_GRAMX")) { gramx_mode = kGramxMeasure; gramx_calls = 0; }
         if (alloc_time_scratch()) return kFail;
         TRMF_HIP_CHECK(hipDeviceSynchronize());
-        return 0;
+        return autotune();
     }
 
     // ---- all-gather helpers ------------------------------------------------------------------------
@@ -785,11 +869,18 @@ struct TrmfSessionImpl {
     hipEvent_t ov_b = nullptr, ov_c[kMaxChunks] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<uint64_t> fcut;               // (world x (chunks + 1)) rows: chunk c of rank r = [fcut[r*(C+1)+c], fcut[r*(C+1)+c+1])
     int fchunks = 0;
-    int overlap_chunks(uint32_t rows) {
+    // The chunk count must be the SAME on every rank (each chunk is one collective): it is derived from the LARGEST block of
+    // the partition, a number every rank computes from the same bounds -- not from the rank's own row count, which differs
+    // between the ranks of an nnz-balanced partition (near 16 / 48 / 64 MiB the ranks disagreed).
+    int overlap_chunks() {
         if (comm->world <= 1 || full || host_col_ptr.empty()) return 0;
         if (const char *e = getenv("TRMF_FOVERLAP")) { const int c = atoi(e); return c <= 0 ? 0 : std::max(2, std::min(kMaxChunks, c)); }
-        const uint64_t bytes = (uint64_t)rows * KP * sizeof(real);
-        return bytes >= kOverlapBytes ? (int)std::max<uint64_t>(2, std::min<uint64_t>(kMaxChunks, bytes / kOverlapBytes)) : 0;
+        uint64_t rows = 0;
+        for (int r = 0; r < comm->world; r++) rows = std::max<uint64_t>(rows, fbounds[r + 1] - fbounds[r]);
+        uint64_t thresh = kOverlapBytes;
+        if (const char *e = getenv("TRMF_FOVERLAP_BYTES")) thresh = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests: the threshold at small sizes
+        const uint64_t bytes = rows * KP * sizeof(real);
+        return bytes >= thresh ? (int)std::max<uint64_t>(2, std::min<uint64_t>(kMaxChunks, bytes / thresh)) : 0;
     }
     int fsolve(PhaseEvents &ev) {
         // the SECOND call is the measured one: the first carries one-time costs on both sides of the comparison (code
@@ -802,7 +893,7 @@ struct TrmfSessionImpl {
         const bool replicate = fs_mode == kShardOff, measure = fs_mode == kShardMeasure && fs_calls == 1;
         const uint32_t rb = replicate ? 0u : (uint32_t)fbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)n : (uint32_t)fbounds[comm->rank + 1];
-        const int C = fs_mode == kShardOn ? overlap_chunks(re - rb) : 0;
+        const int C = fs_mode == kShardOn ? overlap_chunks() : 0;
         if (C >= 2) {
             const int W_ = comm->world;
             if (!side) {
@@ -1027,7 +1118,7 @@ struct TrmfSessionImpl {
     template <int MODE, bool SHARD> void launch_hv_tile_as(const HvVecs &a, int it, int last, const double *rec_in, double *rec_out) {
         const size_t lds = hv_tile_lds_bytes(tile_TI, midx, KP, nlag, k);
         const TileShard &sh = SHARD ? tsh_rank : tsh;
-        const PeerTable *pt = (SHARD && p2p.on) ? peer_table.p : nullptr;
+        const PeerTable *pt = (SHARD && p2p_use) ? peer_table.p : nullptr;
         const int mi = rec_out == xm[0] ? 0 : rec_out == xm[1] ? 1 : 2;
 #define TRMF_LAUNCH_HV_KQ(KQ)                                                                                        \
         hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ, SHARD>), dim3(sh.ntiles), dim3(256), lds, stream, xp, xstate.p, a, sh, it, last,  \
@@ -1060,13 +1151,13 @@ struct TrmfSessionImpl {
     // the slower rank's acceptance test has yet to read (seen as ranks disagreeing on |g| and on the CG's stop: timeouts).
     void p2p_fence(const TileShard &sh) {
         hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, 1, ++p2p.epoch[1], xstate.p, -1, sh, 0, KP, 0,
-                           (real *)nullptr, (real *)nullptr, (real *)nullptr);
+                           (real *)nullptr, (real *)nullptr, (real *)nullptr, kP2pTimeoutTicks);
     }
     int exchange(int mi, int it, int nvec, real *v0, real *v1, real *v2) {
         const int edgeN = midx * KP;
-        if (p2p.on) {
+        if (p2p_use) {
             hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, mi, ++p2p.epoch[mi], xstate.p, it, tsh_rank,
-                               edgeN, KP, nvec, v0, v1, v2);
+                               edgeN, KP, nvec, v0, v1, v2, kP2pTimeoutTicks);
             return 0;
         }
         if (comm->allgather_slots(xm[mi], (size_t)tsh_rank.slot_dbl * sizeof(double), stream)) return kFail;
@@ -1094,7 +1185,7 @@ struct TrmfSessionImpl {
         if (shard && exchange(0, 0, 3, dbuf[0], rbuf[0], hbuf[0])) return kFail;
         // host-followed progress only where an exchange costs a collective; peer to peer (and on one rank) the launches of
         // iterations that will not run are no-ops on the device and everything is enqueued at once
-        const bool follow = shard && !p2p.on;
+        const bool follow = shard && !p2p_use;
         int upto = follow ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
         for (int it = 1; it <= maxcg; it++) {                              // launch `maxcg` only closes the last iteration
             a.v = dbuf[(it - 1) & 1]; a.r_in = rbuf[(it - 1) & 1]; a.hd_in = hbuf[(it - 1) & 1];
@@ -1113,7 +1204,7 @@ struct TrmfSessionImpl {
         }
         // close the last completed iteration: s, w_new = w + s, the sums of the acceptance test (+ the edge rows of s)
         const TileShard &sh = shard ? tsh_rank : tsh;
-        const PeerTable *pt = (shard && p2p.on) ? peer_table.p : nullptr;
+        const PeerTable *pt = (shard && p2p_use) ? peer_table.p : nullptr;
         if (shard)
             hipLaunchKernelGGL(cg_close_kernel<true>, dim3(sh.ntiles), dim3(256), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
                                dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
@@ -1132,24 +1223,33 @@ struct TrmfSessionImpl {
         if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return 0;
     }
-    // Replicated or time-sharded CG?  Measured once, like the other shard decisions: X phases 0 and 1 run replicated
-    // (the second one timed), 2 and 3 time-sharded (the second one timed); the times of every rank are exchanged and
-    // the slower rank decides.  Both forms give bit-identical iterates, so switching between iterations is free.
-    int decide_timeshard() {
+    // Which form of the X-solve?  Measured once, like the other shard decisions: each candidate of init_x_forms() runs two X
+    // phases, the second timed; the times of every rank are exchanged and the slowest rank's time decides.  All forms of the
+    // fused path give bit-identical iterates (the unfused transports likewise among themselves), so switching between
+    // iterations is free.  The measurement starts only once the X-side Gram build has taken its own decision (ADVICE r3:
+    // timing the replicated form while the Gram build was still in ITS measuring mode biased the comparison).
+    int decide_x_form() {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        const double mine[2] = {(double)ts_ms[0], (double)ts_ms[1]};
-        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 2 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
+        double mine[4] = {(double)x_ms[0], (double)x_ms[1], (double)x_ms[2], 0};
+        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 4 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
         std::vector<uint64_t> off(comm->world + 1);
         for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * sizeof mine;
         if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<double> all((size_t)2 * comm->world);
+        std::vector<double> all((size_t)4 * comm->world);
         TRMF_HIP_CHECK(hipMemcpy(all.data(), gramx_times.p, all.size() * sizeof(double), hipMemcpyDeviceToHost));
-        double t_rep = 0, t_ts = 0;
-        for (int r = 0; r < comm->world; r++) { t_rep = std::max(t_rep, all[2 * r]); t_ts = std::max(t_ts, all[2 * r + 1]); }
-        ts_mode = t_ts < t_rep ? kTsOn : kTsOff;
-        if (verbose && comm->rank == 0)
-            fprintf(stderr, ">> X-solve: replicated CG %.3f ms vs time-sharded %.3f ms -> %s\n", t_rep, t_ts, ts_mode == kTsOn ? "time-sharded" : "replicated");
+        int best = x_cands[0];
+        for (int f : x_cands) {
+            x_ms_all[f] = 0;
+            for (int r = 0; r < comm->world; r++) x_ms_all[f] = std::max(x_ms_all[f], all[4 * r + f]);
+            if (x_ms_all[f] < x_ms_all[best]) best = f;
+        }
+        x_form = best;
+        if (verbose && comm->rank == 0) {
+            fprintf(stderr, ">> X-solve:");
+            for (int f : x_cands) fprintf(stderr, " %s %.3f ms;", x_form_name(f), x_ms_all[f]);
+            fprintf(stderr, " -> %s\n", x_form_name(x_form));
+        }
         return 0;
     }
     // Multi-GPU, unfused path: shard the cached-Gram product of every CG step.  It pays when the
@@ -1194,10 +1294,12 @@ struct TrmfSessionImpl {
             wn_slots = std::max(1, std::min(nbe, kMaxPartials / W_));
             if (umsg.alloc((size_t)W_ * std::max(1u, ush.slot_dbl))) return kFail;
             umsg_ptr = umsg.p;
-            if (e && e[0] == 'p') {        // peer to peer: the edge message and the partial-sum arrays live in the IPC-exported arena
+            // peer to peer: the edge messages and the partial-sum arrays live in the IPC-exported arena -- required under
+            // TRMF_CG=p2p, otherwise tried so that the measure-once rule can consider it (init_x_forms)
+            if ((e && e[0] == 'p') || (!e && !getenv("TRMF_NO_P2P"))) {
                 release_p2p();
-                if (setup_p2p(std::max((size_t)W_ * ush.slot_dbl, (size_t)P_NSLOTS * xp.pstride))) return kFail;
-                pbase_override = xm[1]; u_exchanges = 0;
+                if (setup_p2p(std::max((size_t)W_ * ush.slot_dbl, (size_t)P_NSLOTS * xp.pstride), e != nullptr)) return kFail;
+                u_exchanges = 0;
             }
             return 0;
         }
@@ -1214,7 +1316,7 @@ struct TrmfSessionImpl {
     int uts_exchange(int it, int nvec, real *v0, real *v1, real *v2, std::initializer_list<PartialRef> arrays) {
         const int W_ = comm->world, edgeN = midx * KP;
         const bool edges = nvec > 0 && edgeN > 0;
-        if (p2p.on) {
+        if (p2p_use) {
             PushList pl{};
             const int tiles = (T + ar_TI - 1) / ar_TI, groups = KP / kArCols;
             for (const PartialRef &a : arrays) {
@@ -1226,7 +1328,7 @@ struct TrmfSessionImpl {
             hipLaunchKernelGGL(uts_push_kernel, dim3(8), dim3(256), 0, stream, peer_table.p, mi, xstate.p, it, ush, xp.pstride, pl, edgeN, KP,
                                edges ? nvec : 0, v0, v1, v2);
             hipLaunchKernelGGL(xchg_sync_kernel, dim3(1), dim3(256), 0, stream, peer_table.p, mi, ++p2p.epoch[mi], xstate.p, it, ush, edgeN, KP,
-                               edges ? nvec : 0, v0, v1, v2);
+                               edges ? nvec : 0, v0, v1, v2, kP2pTimeoutTicks);
             TRMF_HIP_CHECK(hipGetLastError());
             return 0;
         }
@@ -1343,34 +1445,42 @@ struct TrmfSessionImpl {
 
     int xsolve(XState *log_x = nullptr, double *log_n = nullptr) {   // log_*: record written by the accept kernel
         XState *st = xstate.p;
-        double *Pb = pbase();
         const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
         const bool fused = tile_TI > 0 && maxcg <= kCgHistCap;
-        bool shard = false, timed = false;
-        if (fused && ts_possible) {
-            if (ts_mode == kTsMeasure && ts_calls == 4 && decide_timeshard()) return kFail;
-            if (ts_mode == kTsOn) shard = true;
-            else if (ts_mode == kTsMeasure) { shard = ts_calls >= 2; timed = ts_calls == 1 || ts_calls == 3; }
-            ts_calls++;
+        bool timed = false;
+        int form = x_form;
+        const bool choice = (fused && ts_possible) || (!fused && uts);
+        if (choice && form < 0) {
+            // the replicated form's Gram build takes its own measure-once decision first (second call measured)
+            if (fused && !cg_shard && gramx_mode == kGramxMeasure && gramx_calls == 2 && gramx_decide()) return kFail;
+            if (fused && gramx_mode == kGramxMeasure && !cg_shard) form = x_cands[0];
+            else if (x_calls == 2 * (int)x_cands.size()) { if (decide_x_form()) return kFail; form = x_form; }
+            else { form = x_cands[x_calls / 2]; timed = (x_calls & 1) != 0; x_calls++; }
         }
-        ts_last = shard;
+        if (!choice) form = kXRep;
+        const bool shard = fused && form != kXRep;
+        const int timed_form = form;
+        select_transport(form == kXTsP2p);
         if (timed) TRMF_HIP_CHECK(hipEventRecord(ts0, stream));
         if (full) {
             if (xprepare_full()) return kFail;                                 // b = Y H, shared Gram H^T H
         } else {
             if (gram_x(shard)) return kFail;                                   // G, b
         }
-        if (p2p.on && (fused ? shard : uts)) p2p_fence(fused ? tsh_rank : ush);
+        if (p2p_use && (fused ? shard : uts)) p2p_fence(fused ? tsh_rank : ush);
+        auto end_timed = [&]() -> int {
+            if (!timed) return 0;
+            TRMF_HIP_CHECK(hipEventRecord(ts1, stream));
+            TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+            TRMF_HIP_CHECK(hipEventElapsedTime(&x_ms[timed_form], ts0, ts1));
+            return 0;
+        };
         if (fused) {
             if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
-            if (timed) {
-                TRMF_HIP_CHECK(hipEventRecord(ts1, stream));
-                TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-                TRMF_HIP_CHECK(hipEventElapsedTime(&ts_ms[shard ? 1 : 0], ts0, ts1));
-            }
-            return 0;
+            return end_timed();
         }
         real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
+        double *Pb = pbase();                                            // after select_transport(): the arena's arrays when peer to peer
         const int ndot = (cg_shard || uts) ? comm->world * apply_slots : nba;     // entries of the apply partial arrays
         // element ranges of the element-wise kernels: everything, or (time-sharded) this rank's timestamps -- cg_init_kernel
         // also covers the halo rows, whose gradient the exchange after the gradient product has delivered
@@ -1386,7 +1496,7 @@ struct TrmfSessionImpl {
         av = ArVecs{};
         av.v = dbuf[0]; av.r_in = rbuf[0];
         if (hv(av, 0, 0, 0, hbuf[0], 1)) return kFail;                   // H d0 and its three dot products
-        const bool follow_u = uts && !p2p.on;                            // peer to peer: everything is enqueued at once, as on one GPU
+        const bool follow_u = uts && !p2p_use;                            // peer to peer: everything is enqueued at once, as on one GPU
         int upto = follow_u ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
         for (int it = 1; it <= maxcg; it++) {                            // launch `maxcg` only closes the last iteration
             av.v = dbuf[(it - 1) & 1]; av.r_in = rbuf[(it - 1) & 1]; av.hd_in = hbuf[(it - 1) & 1];
@@ -1411,7 +1521,7 @@ struct TrmfSessionImpl {
                            W.p, log_x, log_n, own_b, own_e);
         TRMF_HIP_CHECK(hipGetLastError());
         if (uts && gather_rows(W.p, ubounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
-        return 0;
+        return end_timed();
     }
 
     // Dynamic LDS above the 64 KB every launch may use needs an explicit opt-in per kernel (gfx950: up to 160 KB
@@ -1454,6 +1564,79 @@ struct TrmfSessionImpl {
         (void)hipStreamSynchronize(stream);
         (void)hipMemcpy(&v, dptr, sizeof(double), hipMemcpyDeviceToHost);
         return v;
+    }
+
+    // ---- measure-once decisions, taken BEFORE the first iteration --------------------------------------------------------
+    // With several ranks three things are decided by measurement (F rows sharded or not, X-side Gram rows sharded or not, the
+    // form of the X-solve); each needs a couple of ordinary iterations and host synchronisations.  autotune() runs those
+    // iterations right after the session is built (and after append_rows, which changes the geometry) on the real problem,
+    // then puts W, H and Theta back and resets the iteration counter: the ALS loop proper never synchronises with the host,
+    // and its timed window -- wherever a caller places it -- contains no measuring iterations.  Every form
+    // computes the same iterates, so the decisions change speed only.  TRMF_AUTOTUNE=0 leaves the decisions to the first
+    // iterations of run() as in round 3.
+    static constexpr int kAutotuneMax = 14;
+    int tuned_iters = 0;
+    bool decisions_pending() const {
+        if (comm->world <= 1 || full) return false;
+        if (fs_mode == kShardMeasure && period_H > 0) return true;
+        if (period_W <= 0) return false;
+        if (x_form < 0) return true;
+        const bool rep_gram = tile_TI > 0 ? x_form == kXRep : (!uts && !cg_shard);
+        return rep_gram && !cg_shard && gramx_mode == kGramxMeasure;
+    }
+    int autotune() {
+        tuned_iters = 0;
+        if (const char *e = getenv("TRMF_AUTOTUNE")) if (atoi(e) == 0) return 0;
+        if (!decisions_pending()) return 0;
+        DevBuf<real> W0, H0, T0;
+        const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;
+        if (W0.alloc(nw, false) || H0.alloc(nh, false) || T0.alloc(nt, false)) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(W0.p, W.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(H0.p, H.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(T0.p, theta.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        const int v = verbose, it0 = iter;
+        const bool ln = log_norms;
+        verbose = 0; log_norms = false;
+        int rc = 0;
+        for (; tuned_iters < kAutotuneMax && decisions_pending() && rc == 0; tuned_iters++) rc = run(1);
+        verbose = v; log_norms = ln; iter = it0;
+        if (rc) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(W.p, W0.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(H.p, H0.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(theta.p, T0.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        if (sync()) return kFail;
+        if (verbose && comm->rank == 0) fprintf(stderr, ">> %s\n", describe().c_str());
+        return 0;
+    }
+    // what this session runs, in one line (trmf_session_describe; bench.py's config.parallelism)
+    std::string describe() const {
+        char buf[640];
+        if (comm->world <= 1) {
+            snprintf(buf, sizeof buf, "1 rank; X-solve %s", tile_TI > 0 ? "fused (one launch per CG step)" : "unfused (AR tile + cached-Gram product per CG step)");
+            return buf;
+        }
+        const bool fused = tile_TI > 0;
+        std::string x;
+        if (full) x = "full-observation path (shared Gram)";
+        else if (fused && ts_possible) x = std::string("fused CG ") + x_form_name(x_form);
+        else if (fused) x = "fused CG replicated (too few tiles to shard over time)";
+        else if (uts) x = std::string("unfused CG ") + x_form_name(x_form);
+        else x = cg_shard ? "unfused CG, cached-Gram product sharded (H d rows gathered per step)" : "unfused CG replicated";
+        std::string meas;
+        for (int f : x_cands) {
+            char t[96];
+            snprintf(t, sizeof t, "%s%s %.3f ms", meas.empty() ? "" : ", ", x_form_name(f), x_ms_all[f]);
+            meas += t;
+        }
+        const bool rep_gram = !full && (fused ? x_form == kXRep : (!uts && !cg_shard));
+        snprintf(buf, sizeof buf, "%d ranks; F rows %s%s; X-side Gram rows %s; %s%s%s%s; peer-to-peer transport %s%s%s; decided in %d set-up iterations",
+                 comm->world, fs_mode == kShardOff ? "replicated" : fs_mode == kShardOn ? "sharded + all-gather of H" : "sharded (undecided)",
+                 (fs_mode == kShardOn && fchunks >= 2) ? " in overlapped chunks" : "",
+                 !rep_gram ? "own timestamps only (never gathered)" : gramx_mode == kGramxReplicate ? "replicated" : gramx_mode == kGramxShard ? "sharded + all-gather of G" : "sharded (undecided)",
+                 x.c_str(), meas.empty() ? "" : " [slowest rank's X phase: ", meas.c_str(), meas.empty() ? "" : "]",
+                 p2p.on ? "available" : "unavailable", p2p.note.empty() ? "" : ": ", p2p.note.c_str(), tuned_iters);
+        return buf;
     }
 
     // ---- the ALS loop (trmf.cpp:647-693) --------------------------------------------------------------------

@@ -284,6 +284,12 @@ double trmf_session_objective(TrmfSession *s) {
     return guard.ok ? IMPL(s)->objective() : NAN;
 }
 double trmf_session_fsolve_bytes(TrmfSession *s) { return s ? IMPL(s)->fsolve_bytes() : 0.0; }
+int32_t trmf_session_describe(TrmfSession *s, char *buf, int32_t cap) {
+    if (!s) return kFail;
+    const std::string d = IMPL(s)->describe();
+    if (buf && cap > 0) { std::strncpy(buf, d.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return (int32_t)d.size();
+}
 void trmf_session_destroy(TrmfSession *s) {
     if (!s) return;
     DeviceGuard guard;

@@ -55,6 +55,7 @@ def bind(lib):
     lib.trmf_session_stats.restype = c_int32
     lib.trmf_session_objective.argtypes = [c_void_p]; lib.trmf_session_objective.restype = c_double
     lib.trmf_session_fsolve_bytes.argtypes = [c_void_p]; lib.trmf_session_fsolve_bytes.restype = c_double
+    lib.trmf_session_describe.argtypes = [c_void_p, ctypes.c_char_p, c_int32]; lib.trmf_session_describe.restype = c_int32
     lib.trmf_session_destroy.argtypes = [c_void_p]; lib.trmf_session_destroy.restype = None
     lib.trmf_dist_get_unique_id.argtypes = [c_void_p]; lib.trmf_dist_get_unique_id.restype = c_int32
     lib.trmf_dist_init.argtypes = [c_int32, c_int32, c_void_p]; lib.trmf_dist_init.restype = c_int32
@@ -147,6 +148,13 @@ class Session(object):
 
     def fsolve_bytes(self):
         return self.lib.trmf_session_fsolve_bytes(self.handle)
+
+    def describe(self):
+        """One line: which phases are sharded, the form of the X-solve the measure-once rule chose (with the measured
+        X-phase time of every candidate) and whether the peer-to-peer transport is available."""
+        buf = ctypes.create_string_buffer(1024)
+        self._check(self.lib.trmf_session_describe(self.handle, buf, len(buf)), 'trmf_session_describe')
+        return buf.value.decode()
 
     def close(self):
         if self.handle:

@@ -184,6 +184,11 @@ TRMF_API double trmf_session_objective(TrmfSession *s);
 /* Algorithmic bytes of ONE F-solve launch on this rank: nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s
  * over the item rows this rank owns. */
 TRMF_API double trmf_session_fsolve_bytes(TrmfSession *s);
+/* One line of text: what the session runs -- with several ranks, which phases are sharded, the form of the X-solve chosen
+ * by the measure-once rule (replicated / time-sharded through the communicator / time-sharded peer to peer) with the
+ * slowest rank's measured X-phase time of every candidate, and whether the peer-to-peer transport is available (and why
+ * not).  Writes at most cap bytes including the terminating NUL; returns the length of the full text. */
+TRMF_API int32_t trmf_session_describe(TrmfSession *s, char *buf, int32_t cap);
 TRMF_API void trmf_session_destroy(TrmfSession *s);
 
 /* --- multi-GPU (one process per GPU; RCCL all-gathers over xGMI) ---------------------------- */

@@ -85,7 +85,7 @@ def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None, dtyp
         tdist.init_host_staged(dtype)
         model = make_model(W0, H0, T0, p['lag_set'])
         with session.Session(Y, model, missing=True, **synth.HYPER) as s:
-            s.run(iters); st = s.stats(iters); s.download()
+            s.run(iters); st = s.stats(iters); s.download(); desc = s.describe()
         # a SECOND session under the same live communicator (its staging buffers remember the first session's stream,
         # which no longer exists): same result
         again = make_model(W0, H0, T0, p['lag_set'])
@@ -97,9 +97,9 @@ def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None, dtyp
         if shape == 'c3full':       # the factors of the full problem stay in the worker: digests + a sample travel
             import hashlib
             dig = [hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest() for a in (model.W, model.H, model.lag_val)]
-            res[name] = (dig, None, None, [x['cg_iter'] for x in st], same, phases)
+            res[name] = (dig, None, None, [x['cg_iter'] for x in st], same, phases, desc)
         else:
-            res[name] = (model.W.copy(), model.H.copy(), model.lag_val.copy(), [x['cg_iter'] for x in st], same, phases)
+            res[name] = (model.W.copy(), model.H.copy(), model.lag_val.copy(), [x['cg_iter'] for x in st], same, phases, desc)
     out.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()

@@ -115,6 +115,77 @@ def test_time_sharded_cg_matches_single_process(world, shape, mode):
             assert cg == cg1 and second_session_same
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('world,shape,env,expect', [
+    (2, 'c4', {}, 'available'), (4, 'c4', {}, 'available'), (8, 'c4', {}, 'available'), (3, 'odd', {}, 'available'),
+    (2, 'c4', {'TRMF_P2P_FAIL': 'alloc'}, 'unavailable'),           # no rank gets its uncached arena
+    (4, 'c4', {'TRMF_P2P_FAIL': 'export:2'}, 'unavailable'),        # ONE rank cannot export: every rank must fall back together
+    (4, 'c4', {'TRMF_P2P_FAIL': 'open:1'}, 'unavailable'),          # one rank cannot map a peer
+    (2, 'c4', {'TRMF_P2P_FAIL': 'fence:0'}, 'unavailable'),         # the trial exchange fails on one rank
+    (2, 'c4', {'TRMF_NO_P2P': '1'}, 'unavailable'),
+    (2, 'c4', {'TRMF_AUTOTUNE': '0'}, 'available'),                 # round-3 behaviour: the decisions inside the first iterations of run()
+])
+def test_default_path_measures_p2p_and_falls_back_safely(world, shape, env, expect):
+    """The NO-FLAG multi-rank path (what `bench.py --gpus N` runs): the peer-to-peer transport is set up as a trial -- IPC arenas,
+    mapping, a flags-only exchange with a 200 ms bound -- and becomes a third candidate of the measure-once rule next to the
+    replicated CG and the time-sharded CG through the communicator; the decisions are taken in set-up iterations whose effect
+    on W / H / Theta is undone, so the run is bit-identical to one process from its first iteration.  When any stage of the
+    set-up fails on ANY rank (env hook), every rank drops the arena, says so in describe(), and the session continues with the
+    communicator forms -- never an error, still bit-identical."""
+    import dist_worker
+    iters = 12 if env.get('TRMF_AUTOTUNE') == '0' else 3
+    out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, shape, env))
+    p, m0 = dist_worker._problem(shape)
+    for dtype in (np.float32, np.float64):
+        name = np.dtype(dtype).name
+        model, cg1 = _single_process(p, m0, dtype, iters)
+        descs = set()
+        for r in range(world):
+            W, H, Th, cg, second_session_same, _, desc = out[r][name]
+            assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val), (r, name)
+            assert cg == cg1 and second_session_same
+            descs.add(desc)
+        assert len(descs) == 1, descs                      # every rank took the same decisions from the same numbers
+        desc = descs.pop()
+        print('world %d %s %s %s: %s' % (world, shape, name, env, desc))
+        assert 'peer-to-peer transport ' + expect in desc, desc
+        assert 'measuring' not in desc and 'undecided' not in desc, desc
+        if expect == 'available':
+            assert 'time-sharded (peer to peer) ' in desc.split('[')[1], desc      # it was a measured candidate
+        else:
+            assert 'peer to peer' not in desc.split('[')[1], desc
+
+
+@pytest.mark.gpu
+def test_overlapped_h_gather_agrees_on_chunk_count_with_uneven_blocks():
+    """the overlapped all-gather of H took its chunk count from the RANK'S OWN row count; an nnz-balanced
+    partition gives the ranks different row counts, so near the size threshold they issued different numbers of
+    collectives.  Here the threshold (TRMF_FOVERLAP_BYTES) is put between the smallest and the largest block of a skewed
+    3-rank partition -- without TRMF_FOVERLAP, so the real rule runs; the old rule would have chosen 0 chunks on one rank and
+    2 on another (a hang).  Now every rank derives the count from the largest block: same count, bit-identical result."""
+    import scipy.sparse as smat
+    import dist_worker
+    from trmf import session
+    world, shape, iters = 3, 'odd', 3
+    p, m0 = dist_worker._problem(shape)
+    bounds = [int(b) for b in session.partition_by_nnz(smat.csc_matrix(p['Y']).indptr, world, dtype=np.float64)]
+    rows = [bounds[r + 1] - bounds[r] for r in range(world)]
+    assert min(rows) < max(rows), rows
+    KP = 16                                                  # k = 5 padded
+    for dtype in (np.float32, np.float64):
+        sz = np.dtype(dtype).itemsize
+        thresh = (min(rows) + max(rows)) // 2 * KP * sz      # smallest block below, largest above
+        assert min(rows) * KP * sz < thresh <= max(rows) * KP * sz
+        env = {'TRMF_FOVERLAP_BYTES': str(thresh), 'TRMF_FSHARD': 'shard', 'TRMF_CG': 'timeshard'}
+        out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, shape, env, (np.dtype(dtype).name,)))
+        model, cg1 = _single_process(p, m0, dtype, iters)
+        for r in range(world):
+            W, H, Th, cg, same, _, desc = out[r][np.dtype(dtype).name]
+            assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val), r
+            assert cg == cg1 and same
+            assert 'overlapped chunks' in desc, desc
+
+
 _C3_REF = {}
 
 
@@ -146,13 +217,18 @@ def test_config4_full_size_sharded_paths_on_one_gpu(world):
     iters = 2
     ref_dig, ref_cg = _c3_single_process_digests(iters)
     report = {}
-    for mode in ('replicate', 'timeshard', 'p2p'):
-        out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c3full', {'TRMF_CG': mode, 'TRMF_FSHARD': 'shard', 'TRMF_GRAMX': 'shard'},
-                          ('float32',)))
+    for mode in ('replicate', 'timeshard', 'p2p', 'auto'):
+        # 'auto': NO switch set -- the path bench.py --gpus N takes: every measure-once decision (F rows, X-side Gram rows, the form
+        # of the CG with the peer-to-peer transport as a candidate) taken in set-up iterations on the full problem
+        env = {} if mode == 'auto' else {'TRMF_CG': mode, 'TRMF_FSHARD': 'shard', 'TRMF_GRAMX': 'shard'}
+        out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c3full', env, ('float32',)))
         for r in range(world):
-            dig, _, _, cg, second_session_same, phases = out[r]['float32']
+            dig, _, _, cg, second_session_same, phases, desc = out[r]['float32']
             assert dig == ref_dig, (mode, r)
             assert cg == ref_cg and second_session_same
+        if mode == 'auto':
+            print('config 4 full size, %d ranks on one GPU, no switches: %s' % (world, out[0]['float32'][6]))
+            assert 'peer-to-peer transport available' in out[0]['float32'][6] and 'measuring' not in out[0]['float32'][6]
         report[mode] = {r: out[r]['float32'][5] for r in range(world)}
         print('config 4 full size, %d ranks on one GPU, CG %s: CG %s; last iteration per rank (ms F / F kernel / X / Theta): %s' % (
             world, mode, ref_cg, ['%.2f/%.2f/%.2f/%.2f' % tuple(report[mode][r][-1]) for r in range(world)]))
