@@ -23,6 +23,7 @@
 
 #include "../../include/trmf_abi.h"
 #include "cg_kernels.hpp"
+#include "cg_persist.hpp"
 #include "comm.hpp"
 #include "full_kernels.hpp"
 #include "common.hpp"
@@ -473,7 +474,7 @@ struct TrmfSessionImpl {
             }
             if (rc) return kFail;
         }
-        tile_TI = 0; nbt = 1;
+        tile_TI = 0; nbt = 1; persist_state = 0;
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
             int TI = hv_tile_rows(k);
             if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
@@ -1223,6 +1224,77 @@ struct TrmfSessionImpl {
         if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return 0;
     }
+    // ---- the X-solve as ONE persistent kernel (cg_persist.hpp) ---------------------------------------------------------------
+    // One rank per GPU and the GPU to itself (world == 1): every tile's workgroup stays resident for the whole solve.  Needs all
+    // workgroups co-resident (checked against the occupancy the runtime reports; cooperative launch) and the LDS of the resident
+    // vectors; otherwise -- or with TRMF_PERSIST=0 -- the launch-per-step path runs.  Bit-identical results either way.
+    DevBuf<unsigned long long> ll_rec, ll_vec;   // tagged records / tagged vector rows (zero = never a valid tag)
+    DevBuf<long long> persist_prof;           // -DTRMF_PERSIST_PROF builds: phase stamps of the last solve (printed by sync())
+    uint32_t persist_epoch = 1;
+    int persist_state = 0;                    // 0: not examined yet, 1: usable, -1: not
+    template <int KQ> int persist_prepare(size_t lds) {
+        const void *fn = reinterpret_cast<const void *>(&cg_persist_kernel<KQ>);
+        if (lds > kLdsMax) return 0;
+        if (lds > kLdsDefault && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        return per_cu * prop.multiProcessorCount;
+    }
+    template <int KQ> int persist_launch(const PersistArgs &pa, size_t lds) {
+        XParams xpv = xp; XState *stp = xstate.p; PersistArgs pav = pa;
+        void *args[] = {&xpv, &stp, &pav};
+        TRMF_HIP_CHECK(hipLaunchCooperativeKernel(reinterpret_cast<const void *>(&cg_persist_kernel<KQ>), dim3(nbt), dim3(256), args, (unsigned)lds, stream));
+        return 0;
+    }
+#define TRMF_PERSIST_SWITCH(CALL)                  \
+        switch (hv_kq(k) / 8) {                    \
+            case 1: CALL(8); break;                \
+            case 2: CALL(16); break;               \
+            case 3: CALL(24); break;               \
+            case 4: CALL(32); break;               \
+            case 5: CALL(40); break;               \
+            case 6: CALL(48); break;               \
+            case 7: CALL(56); break;               \
+            default: CALL(64); break;              \
+        }
+    bool persist_usable(int maxcg) {
+        if (persist_state == 0) {
+            persist_state = -1;
+            const char *e = getenv("TRMF_PERSIST");
+            const size_t lds = persist_lds_bytes(tile_TI, midx, KP, nlag, k, nbt);
+            if (comm->world == 1 && tile_TI > 0 && nbt <= kPersistMaxTiles && maxcg <= kCgHistCap && !(e && atoi(e) == 0)) {
+                int slots = 0;
+#define TRMF_PERSIST_PREP(KQV) slots = persist_prepare<KQV>(lds)
+                TRMF_PERSIST_SWITCH(TRMF_PERSIST_PREP)
+#undef TRMF_PERSIST_PREP
+                if (slots >= nbt && ll_rec.alloc((size_t)2 * nbt * kLLWords) == 0 &&
+                    ll_vec.alloc((size_t)2 * T * KP * (2 * sizeof(real) / sizeof(unsigned long long))) == 0) persist_state = 1;
+            }
+        }
+        return persist_state == 1;
+    }
+    int xsolve_persist(int maxcg, XState *log_x, double *log_n) {
+        PersistArgs pa{};
+        pa.W = W.p; pa.Bv = Bv.p; pa.G = Gmat(); pa.lag_set = lag_set.p; pa.theta = theta.p;
+        pa.hll = ll_vec.p; pa.ll = ll_rec.p;
+        pa.epoch0 = persist_epoch; pa.TI = tile_TI; pa.maxcg = maxcg; pa.log_x = log_x; pa.log_n = log_n;
+        persist_epoch += (uint32_t)maxcg + 8;
+#if defined(TRMF_PERSIST_PROF)
+        if (getenv("TRMF_PERSIST_PROF")) {
+            if (!persist_prof.p && persist_prof.alloc((size_t)2 * kProfIters * kProfSlots + 2 * (size_t)kPersistMaxTiles)) return kFail;
+            pa.prof = persist_prof.p;
+        }
+#endif
+        const size_t lds = persist_lds_bytes(tile_TI, midx, KP, nlag, k, nbt);
+#define TRMF_PERSIST_GO(KQV) if (persist_launch<KQV>(pa, lds)) return kFail
+        TRMF_PERSIST_SWITCH(TRMF_PERSIST_GO)
+#undef TRMF_PERSIST_GO
+        return 0;
+    }
+#undef TRMF_PERSIST_SWITCH
+
     // Which form of the X-solve?  Measured once, like the other shard decisions: each candidate of init_x_forms() runs two X
     // phases, the second timed; the times of every rank are exchanged and the slowest rank's time decides.  All forms of the
     // fused path give bit-identical iterates (the unfused transports likewise among themselves), so switching between
@@ -1476,7 +1548,8 @@ struct TrmfSessionImpl {
             return 0;
         };
         if (fused) {
-            if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
+            if (!shard && persist_usable(maxcg)) { if (xsolve_persist(maxcg, log_x, log_n)) return kFail; }
+            else if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
             return end_timed();
         }
         real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
@@ -1553,7 +1626,7 @@ struct TrmfSessionImpl {
 
     // ---- ||.||^2 into a log slot ----------------------------------------------------------------------------
     int log_norm(const real *v, size_t count, double *dst) {
-        const int nb = (int)std::min<size_t>(kMaxPartials, (count + 255) / 256);
+        const int nb = (int)std::max<size_t>(1, std::min<size_t>(kMaxPartials, (count + 255) / 256));    // count == 0 (no lags): one block, sum 0
         hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, stream, v, count, P(P_DOT));
         hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, stream, P(P_DOT), nb, dst);
         return 0;
@@ -1613,7 +1686,8 @@ struct TrmfSessionImpl {
     std::string describe() const {
         char buf[640];
         if (comm->world <= 1) {
-            snprintf(buf, sizeof buf, "1 rank; X-solve %s", tile_TI > 0 ? "fused (one launch per CG step)" : "unfused (AR tile + cached-Gram product per CG step)");
+            snprintf(buf, sizeof buf, "1 rank; X-solve %s", tile_TI <= 0 ? "unfused (AR tile + cached-Gram product per CG step)"
+                     : persist_state == 1 ? "fused, one persistent kernel per solve" : persist_state == 0 ? "fused (not run yet)" : "fused, one launch per CG step");
             return buf;
         }
         const bool fused = tile_TI > 0;
@@ -1696,6 +1770,35 @@ struct TrmfSessionImpl {
 
     int sync() {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+#if defined(TRMF_PERSIST_PROF)
+        if (persist_prof.p) {
+            std::vector<long long> hp((size_t)2 * kProfIters * kProfSlots + 2 * (size_t)kPersistMaxTiles);
+            TRMF_HIP_CHECK(hipMemcpy(hp.data(), persist_prof.p, hp.size() * sizeof(long long), hipMemcpyDeviceToHost));
+            for (int sel = 0; sel < 2; sel++) {
+                const long long t0 = hp[(size_t)sel * kProfIters * kProfSlots];
+                for (int i = 0; i < kProfIters; i++) {
+                    const long long *r = hp.data() + ((size_t)sel * kProfIters + i) * kProfSlots;
+                    if (!r[0] && !r[3]) continue;
+                    fprintf(stderr, "PERSIST_PROF tile %s row %2d:", sel ? "mid" : "0  ", i);
+                    for (int q = 0; q < kProfSlots; q++) fprintf(stderr, " %8.2f", r[q] ? (r[q] - t0) * 0.01 : 0.0);
+                    fprintf(stderr, "  us\n");
+                }
+            }
+            {   // CG iteration 5 of every tile, relative to the earliest collect: when its collect finished, when it published
+                const long long *q = hp.data() + (size_t)2 * kProfIters * kProfSlots;
+                long long base = 0;
+                for (int t = 0; t < nbt; t++) if (q[2 * t] && (!base || q[2 * t] < base)) base = q[2 * t];
+                fprintf(stderr, "PERSIST_TILES");
+                for (int t = 0; t < nbt; t++) fprintf(stderr, " %.2f/%.2f", (q[2 * t] - base) * 0.01, (q[2 * t + 1] - base) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
+        if (persist_state == 1) {   // a bounded poll of the persistent CG kernel ran out (never observed; the GPU must not hang)
+            XState hx;
+            TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));
+            if (hx.p2p_error) { set_error("persistent CG kernel: an exchange between workgroups timed out (is another process using the GPU? TRMF_PERSIST=0 selects the launch-per-step path)"); return kFail; }
+        }
         if (p2p.on) {               // a bounded wait of the peer-to-peer exchange ran out: the factors are not to be trusted
             XState hx;
             TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));

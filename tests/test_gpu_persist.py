@@ -1,0 +1,86 @@
+"""The persistent CG kernel (csrc/cg_persist.hpp: one cooperative launch per X-solve, workgroups exchanging tagged records
+through memory) against the launch-per-step path it replaces on one GPU: same tiles, same element mapping, same summation
+order, so the factors, the CG counts and every number of the TRON line must be BIT-IDENTICAL.  The other parity tests
+(goldens, fuzz, full size) run through the persistent kernel by default and compare it with the oracle; the launch-per-step
+kernels stay covered here, by the multi-rank tests and by the multi-wave grids of test_gpu_fullsize.py."""
+import numpy as np
+import pytest
+
+from helpers import make_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(p, m0, dtype, iters, missing, monkeypatch, persist):
+    from trmf import session, synth
+    if persist:
+        monkeypatch.delenv('TRMF_PERSIST', raising=False)
+    else:
+        monkeypatch.setenv('TRMF_PERSIST', '0')
+    model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
+    Y = p['Y'].astype(dtype)
+    with session.Session(Y, model, missing=missing, **synth.HYPER) as s:
+        s.run(iters); st = s.stats(iters); s.download(); desc = s.describe()
+    return model, st, desc
+
+
+@pytest.mark.parametrize('shape', [
+    dict(n=900, T=400, k=12, nlag=4, density=0.06),          # two column tiles
+    dict(n=701, T=353, k=5, nlag=3, density=0.08),           # odd rank, short last tile
+    dict(n=3000, T=1200, k=40, nlag=16, density=0.04),       # config 3 / 4's rank and lag set
+    dict(n=2000, T=2500, k=16, nlag=8, density=0.02),        # config 2's
+    dict(n=1500, T=700, k=64, nlag=6, density=0.05),         # the widest Gram slice (8-byte Gram loads in fp32)
+    dict(n=400, T=300, k=8, nlag=0, density=0.1),            # no lags at all
+    dict(n=600, T=260, k=24, nlag=5, density=0.08, lags=[0, 1, 2, 7, 24]),     # lag 0 is legal (trmf.py:354)
+])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_persistent_kernel_bit_identical_to_launch_per_step(shape, dtype, monkeypatch):
+    from trmf import synth
+    c = dict(shape)
+    lags = c.pop('lags', None)
+    p = synth.sparse_problem(n=c['n'], T=c['T'], k=c['k'], nlag=c['nlag'], density=c['density'], dtype=np.float64, seed=5)
+    if lags is not None:
+        p['lag_set'] = np.array(lags, dtype=np.uint32)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], c['k'], seed=5)
+    iters = 4
+    a, sa, da = _run(p, m0, dtype, iters, True, monkeypatch, persist=True)
+    b, sb, db = _run(p, m0, dtype, iters, True, monkeypatch, persist=False)
+    if 'unfused' in da:
+        pytest.skip('lag reach does not fit the fused tile: ' + da)
+    assert 'persistent' in da and 'one launch per CG step' in db, (da, db)
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H) and np.array_equal(a.lag_val, b.lag_val)
+    for x, y in zip(sa, sb):
+        for key in ('f', 'fnew', 'actred', 'prered', 'gnorm', 'cg_rnorm', 'cg_iter', 'accepted', 'delta', 'normF', 'normX', 'normLV'):
+            assert x[key] == y[key], (key, x[key], y[key])
+
+
+@pytest.mark.parametrize('dense', [False, True])
+def test_persistent_kernel_full_observation_path(dense, monkeypatch):
+    """missing = 0: one shared Gram for every timestamp (gstride 0) -- the fused CG covers it when the lag reach is short."""
+    from trmf import synth
+    p = synth.dense_problem(300, 500, 6, [1, 2, 3], dtype=np.float64, seed=3)
+    if not dense:
+        import scipy.sparse as smat
+        p = dict(p, Y=smat.csr_matrix(p['Y']))
+    m0 = synth.initial_model(p['Y'], p['lag_set'], 6, seed=3)
+    for dtype in (np.float32, np.float64):
+        a, sa, da = _run(p, m0, dtype, 4, False, monkeypatch, persist=True)
+        b, sb, db = _run(p, m0, dtype, 4, False, monkeypatch, persist=False)
+        assert 'persistent' in da and 'one launch per CG step' in db, (da, db)
+        assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H) and np.array_equal(a.lag_val, b.lag_val)
+        assert [x['cg_iter'] for x in sa] == [x['cg_iter'] for x in sb]
+
+
+def test_persistent_kernel_early_stop_and_iteration_cap(monkeypatch):
+    """Both ends of the CG: a start so close to the optimum that the gradient (or the first step) meets the tolerance, and an
+    ill-conditioned start that runs into the 20-step cap."""
+    from trmf import session, synth
+    p = synth.sparse_problem(n=800, T=300, k=16, nlag=4, density=0.08, dtype=np.float64, seed=9)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], 16, seed=9)
+    for dtype in (np.float32, np.float64):
+        a, sa, _ = _run(p, m0, dtype, 12, True, monkeypatch, persist=True)
+        b, sb, _ = _run(p, m0, dtype, 12, True, monkeypatch, persist=False)
+        assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H)
+        cg = [x['cg_iter'] for x in sa]
+        assert cg == [x['cg_iter'] for x in sb]
+        assert max(cg) == 20 and min(cg) < 20, cg
