@@ -14,6 +14,9 @@ SHAPES = {
     'small': dict(n=900, T=400, k=12, nlag=4, density=0.06),
     'odd': dict(n=701, T=353, k=5, nlag=3, density=0.08),
     'c4': dict(n=3000, T=1200, k=40, nlag=16, density=0.04),       # BASELINE config 4's rank and lag set, scaled down
+    # BASELINE config 5's rank, lag set and element type (k = 64, |L| = 32, fp64; sizes scaled to a one-GPU test): the unfused CG
+    # with KP = 64, apply_kernel<true, 17> on packed Grams, midx = 32
+    'c5s': dict(n=40000, T=6000, k=64, nlag=32, density=0.005),
 }
 
 

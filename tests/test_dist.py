@@ -290,6 +290,44 @@ def test_time_sharded_unfused_cg(world, transport, monkeypatch):
         assert out[0][name][4]      # second session under the same communicator
 
 
+_C5S_REF = {}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('world', [2, 4, 8])
+@pytest.mark.parametrize('mode', ['comm', 'p2p', 'shard', 'auto'])
+def test_config5_shape_multi_rank(world, mode):
+    """Config 5's own kernel set with several ranks: k = 64, |L| = 32, fp64 -- the UNFUSED CG with KP = 64,
+    `apply_kernel<true, 17>` on packed Grams, midx = 32, and the all-gather of H in 4 overlapped chunks under the F-solve (the size
+    threshold lowered with TRMF_FOVERLAP_BYTES so that the REAL rule picks the chunks at this test's size; config 5's 64 MB blocks
+    give 4 chunks by themselves).  'comm': time-sharded unfused CG, grouped exchange through the communicator; 'p2p': the same peer
+    to peer; 'shard': the round-2 form (Gram product sharded, H d rows gathered per step); 'auto': no CG switch -- the
+    measure-once rule chooses between the two transports.  Ranks bit-identical to each other, within 1e-9 of the single-process
+    run (the partial sums of the product are grouped per rank), CG counts equal."""
+    import dist_worker
+    iters = 2
+    env = {'TRMF_FOVERLAP_BYTES': str(1 << 20), 'TRMF_FSHARD': 'shard'}
+    if mode == 'comm':
+        env['TRMF_CG'] = 'timeshard'
+    elif mode in ('p2p', 'shard'):
+        env['TRMF_CG'] = mode
+    out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, 'c5s', env, ('float64',)))
+    if 'ref' not in _C5S_REF:
+        p, m0 = dist_worker._problem('c5s')
+        _C5S_REF['ref'] = _single_process(p, m0, np.float64, iters)
+    model, cg1 = _C5S_REF['ref']
+    W0, H0, T0, cg0, same0, _, desc = out[0]['float64']
+    print('config 5 shape, %d ranks, %s: %s' % (world, mode, desc))
+    for r in range(1, world):
+        W, H, Th, cg = out[r]['float64'][:4]
+        assert np.array_equal(W0, W) and np.array_equal(H0, H) and np.array_equal(T0, Th) and cg0 == cg, r
+    assert relfro(W0, model.W) < 1e-9 and relfro(H0, model.H) < 1e-9 and relfro(T0, model.lag_val) < 1e-8
+    assert cg0 == cg1 and same0
+    assert 'unfused CG' in desc and 'overlapped chunks' in desc, desc
+    if mode == 'auto':
+        assert 'measuring' not in desc and 'peer-to-peer transport available' in desc, desc
+
+
 @pytest.mark.gpu
 def test_two_ranks_one_gpu_sharded_cg_gram_product(monkeypatch):
     """The sharded form of the CG (unfused path: every rank multiplies its own timestamps' cached Grams, the rows of
