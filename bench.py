@@ -329,6 +329,11 @@ def main():
                 np.savez(gpu_file, W=m2.W, H=m2.H, lag_val=m2.lag_val)
             base = cpu_baseline(args.config, args.cpu_iters, state_file, gpu_file)
             if base is not None:
+                # the CPU runs its first `cpu_iters` iterations from the state the GPU's timed window started from; later iterations
+                # run shorter CG solves, so the like-for-like GPU figure is the one over the SAME iterations, from the
+                # per-iteration HIP-event phase times
+                w = st[:min(args.cpu_iters, len(st))]
+                base['gpu_same_window'] = {'iters': len(w), 'iter_per_s': 1e3 * len(w) / sum(x['ms_F'] + x['ms_X'] + x['ms_LV'] for x in w)}
                 out['cpu_baseline'] = base
             for f in (state_file, gpu_file):
                 if f and os.path.exists(f):

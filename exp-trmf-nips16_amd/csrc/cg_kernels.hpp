@@ -33,6 +33,7 @@ struct XState {
     // stop (kCgRunning until then), buffer that holds the final r
     double rho_hist[kCgHistCap + 2];
     int stop_it, r_parity;
+    double rho_direct;            // |-g - H s|^2 of the step evaluated DIRECTLY (persistent kernel; -1 elsewhere): the CG's own r^T r is a recurrence
     int p2p_error;                // a peer-to-peer exchange of the time-sharded CG timed out (sticky; reported by sync())
     long long p2p_diag[4];        // the first timeout: message index, launch (it), peer, expected epoch, flag value seen
 };
@@ -130,7 +131,8 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const real *__restri
 // (the halo is recomputed, not exchanged) and applies the adjoint to its own rows.  Arithmetic and rounding
 // sequence of trmf.cpp:99-149 (residual in double, every accumulation into the result rounded to val_type).
 // FUSE_DIR: the operand is the new direction d + (beta-1) d + r (rf_tron.h:494-502), written once for the own rows.
-// Partial sums of r^2 (AR part of fun) and v^2 (ridge part) go to slot blockIdx.y * gridDim.x + blockIdx.x.
+// Partial sums of r^2 (AR part of fun) and v^2 (ridge part) go to slot (tile0 + blockIdx.x) * gridDim.y + blockIdx.y (tile-major:
+// the slots of a rank's tiles are one contiguous range).
 constexpr int kArCols = 8;
 constexpr int kArPitch = kArCols + 1; // LDS row pitch in elements: a thread owns kArU = 8 CONSECUTIVE rows of one column, so the 8 row groups of a
                                       // wavefront sit 8 rows apart -- with 9 elements per row they fall into different bank groups (fp32 and fp64)
@@ -1393,10 +1395,11 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
         else if (actred < 0.75 * prered) delta = fmax(0.25 * delta, fmin(alpha * snorm, 4.0 * delta));
         else delta = fmax(delta, fmin(alpha * snorm, 4.0 * delta));
         st->delta = delta;
+        st->rho_direct = -1.0;
         if (log_x) {                                    // iteration record written here: no copies on the stream
             log_x->f = f; log_x->fnew = fnew; log_x->gnorm = st->gnorm; log_x->cg_rnorm = sqrt(rho);
             log_x->actred = actred; log_x->prered = prered; log_x->gs = gs; log_x->sr = sr;
-            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0; log_x->delta = delta;
+            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0; log_x->delta = delta; log_x->rho_direct = -1.0;
             log_norms[0] = log_norms[1] = log_norms[2] = -1.0;      // ||.||^2 lines are off in this mode
         }
     }
@@ -1504,6 +1507,7 @@ __global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__r
         st->prered = prered; st->actred = actred;
         st->accepted = accept ? 1 : 0;
         st->cg_rnorm = sqrt(rho);
+        st->rho_direct = -1.0;
         double delta = fmin(st->gnorm, snorm);          // trust-region bound of the TRON line: see accept_kernel
         const double curv = fnew - f - gs;
         const double alpha = curv <= 0 ? 4.0 : fmax(0.25, -0.5 * (gs / curv));
@@ -1515,7 +1519,7 @@ __global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__r
         if (log_x) {                                    // iteration record written here: no copies on the stream
             log_x->f = f; log_x->fnew = fnew; log_x->gnorm = st->gnorm; log_x->cg_rnorm = sqrt(rho);
             log_x->actred = actred; log_x->prered = prered; log_x->gs = gs; log_x->sr = sr;
-            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0; log_x->delta = delta;
+            log_x->cgtol = st->cgtol; log_x->cg_iter = st->cg_iter; log_x->accepted = accept ? 1 : 0; log_x->delta = delta; log_x->rho_direct = -1.0;
             log_norms[0] = log_norms[1] = log_norms[2] = -1.0;      // ||.||^2 lines are off in this mode
         }
     }

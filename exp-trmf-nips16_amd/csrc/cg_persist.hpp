@@ -580,24 +580,29 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     double cs[4];
     if (!collect(xi, 3, cs, true, vs)) return;             // + the halo rows of s (vs: the direction is no longer needed)
     xi++;
+    if (tid == 0) { keep[3] = cs[0]; keep[4] = cs[1]; keep[5] = cs[2]; }     // parked across the product below (registers)
 
     // =========================== H s and the acceptance test (hv_tile_kernel<HV_PLAIN>, accept_tile_kernel) ===========================
     for (int e = tid; e < own_n; e += 256) vs[own0 + e] = sown[e];
     for (int e = own_n + tid; e < TI * KP; e += 256) vs[own0 + e] = 0;     // a short last tile: rows past T
     __syncthreads();
-    double sHs = 0, unused2 = 0;
+    double sHs = 0, unused2 = 0, rdir = 0, unused3 = 0;
     if (ar_on) ar_residuals(unused2);
     __syncthreads();
     product([&](int rr, int i, int tcol, int tpos, real x, double ac, double od) {
         const real oc = (real)(od + ac);
         sHs += (double)x * (double)oc;
+        // the residual of the step evaluated directly, -g - H s: the CG's own r^T r is the recurrence rho - 2 alpha <r,Hd> +
+        // alpha^2 <Hd,Hd>, and the stop test reads it (its drift against the direct norm is on record now)
+        const double rt = (double)gown[rr * KP + tpos] + (double)oc;
+        rdir += rt * rt;
     });
-    sHs = block_allsum(sHs, smem);
-    if (tid == 0) publish(xi, 0, 0, sHs, 0);
+    block_allsum3(sHs, rdir, unused3, smem);
+    if (tid == 0) publish(xi, rdir, 0, sHs, 0);
     double ps[4];
     if (!collect(xi, 3, ps, false, nullptr)) return;
-    const double gsr = (double)(real)cs[0], srr = (double)(real)cs[1];           // BLAS dots in val_type (rf_tron.h:186-187)
-    const double snorm = sqrt((double)(real)cs[2]);
+    const double gsr = (double)(real)keep[3], srr = (double)(real)keep[4];       // BLAS dots in val_type (rf_tron.h:186-187)
+    const double snorm = sqrt((double)(real)keep[5]);
     const double prered = -0.5 * (gsr - srr);                                    // rf_tron.h:190
     const double actred = -(gsr + 0.5 * ps[2]);                                  // = f - f(w+s), exactly
     const double f = keep[0], gnorm = keep[1], rho_stop = keep[2];               // (written before many barriers ago)
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         const double rho = (double)(real)rho_stop;
         st->f = f; st->fnew = fnew; st->gnorm = gnorm; st->cgtol = cgtol; st->gs = gsr; st->sr = srr;
         st->prered = prered; st->actred = actred; st->accepted = accept ? 1 : 0; st->cg_iter = cg_iter;
-        st->stop_it = stop_it; st->r_parity = stop_it & 1; st->cg_rnorm = sqrt(rho);
+        st->stop_it = stop_it; st->r_parity = stop_it & 1; st->cg_rnorm = sqrt(rho); st->rho_direct = ps[0];
         double delta = fmin(gnorm, snorm);                                       // trust-region bound of the TRON line: see accept_kernel
         const double curv = fnew - f - gsr;
         const double al = curv <= 0 ? 4.0 : fmax(0.25, -0.5 * (gsr / curv));
@@ -623,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             XState *lx = a.log_x;
             lx->f = f; lx->fnew = fnew; lx->gnorm = gnorm; lx->cg_rnorm = sqrt(rho);
             lx->actred = actred; lx->prered = prered; lx->gs = gsr; lx->sr = srr;
-            lx->cgtol = cgtol; lx->cg_iter = cg_iter; lx->accepted = accept ? 1 : 0; lx->delta = delta;
+            lx->cgtol = cgtol; lx->cg_iter = cg_iter; lx->accepted = accept ? 1 : 0; lx->delta = delta; lx->rho_direct = ps[0];
             a.log_n[0] = a.log_n[1] = a.log_n[2] = -1.0;
         }
     }

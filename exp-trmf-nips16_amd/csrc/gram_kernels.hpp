@@ -961,8 +961,14 @@ struct QuadStream {
 #ifndef TRMF_QUAD_WAVES
 #define TRMF_QUAD_WAVES 3
 #endif
+// Four column tiles (rank 49..64) need more than the 168 registers of three wavefronts per SIMD: at that bound the <4,56> and
+// <4,64> instantiations spilled 296 / 460 bytes per lane; they are built for two wavefronts per SIMD instead.
+#ifndef TRMF_QUAD_WAVES4
+#define TRMF_QUAD_WAVES4 2      // (3 reproduces round 3's spilling build for the comparison in profiles/r04_fsolve_k64_fp32.txt)
+#endif
+constexpr int quad_waves(int NT) { return NT >= 4 ? TRMF_QUAD_WAVES4 : TRMF_QUAD_WAVES; }
 template <int NT, int KMAX, int ABL = 0>
-__global__ __launch_bounds__(256, TRMF_QUAD_WAVES) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
+__global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,
                                                           const float *__restrict__ val,
                                                           const float *__restrict__ X,

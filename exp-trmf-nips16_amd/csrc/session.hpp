@@ -1838,6 +1838,7 @@ struct TrmfSessionImpl {
             o.normF = hl.normF; o.normX = hl.normX; o.normLV = hl.normLV;
             o.f = hl.x.f; o.fnew = hl.x.fnew; o.actred = hl.x.actred; o.prered = hl.x.prered;
             o.gnorm = hl.x.gnorm; o.cg_rnorm = hl.x.cg_rnorm; o.cg_iter = hl.x.cg_iter; o.accepted = hl.x.accepted; o.delta = hl.x.delta;
+            o.cg_rnorm_direct = hl.x.rho_direct >= 0 ? std::sqrt(hl.x.rho_direct) : -1.0;
             o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = 0;
             (void)hipEventElapsedTime(&o.ms_F, ev.f0, ev.f1);
             (void)hipEventElapsedTime(&o.ms_F_kernel, ev.fk0, ev.fk1);

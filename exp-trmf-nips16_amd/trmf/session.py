@@ -20,7 +20,7 @@ class TrmfIterStats(ctypes.Structure):
                 ('gnorm', c_double), ('cg_rnorm', c_double),
                 ('cg_iter', c_int32), ('accepted', c_int32),
                 ('ms_F', c_float), ('ms_X', c_float), ('ms_LV', c_float), ('ms_F_kernel', c_float),
-                ('delta', c_double)]
+                ('delta', c_double), ('cg_rnorm_direct', c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}

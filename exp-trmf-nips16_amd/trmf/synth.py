@@ -62,6 +62,9 @@ CONFIGS = {
     'c2': dict(n=10000, T=5000, k=16, nlag=8, density=0.01, dtype='float32'),
     'c3': dict(n=100000, T=10000, k=40, nlag=16, density=0.01, dtype='float32'),
     'c5': dict(n=1000000, T=50000, k=64, nlag=32, density=0.001, dtype='float64'),
+    # measurement aids: config 3's sizes at the fp32 ranks whose F-solve needs four column tiles (scripts/bench_fsolve.py)
+    'c3k56': dict(n=100000, T=10000, k=56, nlag=16, density=0.01, dtype='float32'),
+    'c3k64': dict(n=100000, T=10000, k=64, nlag=16, density=0.01, dtype='float32'),
     # small shapes for tests
     'tiny': dict(n=300, T=200, k=8, nlag=3, density=0.05, dtype='float32'),
     'small40': dict(n=2000, T=600, k=40, nlag=16, density=0.03, dtype='float32'),

@@ -133,6 +133,8 @@ typedef struct {
     float ms_F, ms_X, ms_LV;               /* HIP-event time of each phase on the solver stream */
     float ms_F_kernel;                     /* HIP-event time of the F-solve kernel alone       */
     double delta;                          /* trust-region bound of the TRON line (rf_tron.h:195-219) */
+    double cg_rnorm_direct;                /* |-g - H s| of the step evaluated directly; cg_rnorm is the CG's recurrence
+                                              (-1 where not evaluated: only the one-GPU persistent kernel does)   */
 } TrmfIterStats;
 
 typedef struct TrmfSession TrmfSession;

@@ -11,7 +11,7 @@ import socket
 import numpy as np
 import pytest
 
-from helpers import make_model, relfro
+from helpers import evidence, make_model, relfro
 
 
 def _free_port():
@@ -227,10 +227,10 @@ def test_config4_full_size_sharded_paths_on_one_gpu(world):
             assert dig == ref_dig, (mode, r)
             assert cg == ref_cg and second_session_same
         if mode == 'auto':
-            print('config 4 full size, %d ranks on one GPU, no switches: %s' % (world, out[0]['float32'][6]))
+            evidence('config 4 full size, %d ranks on one GPU, no switches: %s' % (world, out[0]['float32'][6]))
             assert 'peer-to-peer transport available' in out[0]['float32'][6] and 'measuring' not in out[0]['float32'][6]
         report[mode] = {r: out[r]['float32'][5] for r in range(world)}
-        print('config 4 full size, %d ranks on one GPU, CG %s: CG %s; last iteration per rank (ms F / F kernel / X / Theta): %s' % (
+        evidence('config 4 full size, %d ranks on one GPU, CG %s: CG %s; last iteration per rank (ms F / F kernel / X / Theta): %s' % (
             world, mode, ref_cg, ['%.2f/%.2f/%.2f/%.2f' % tuple(report[mode][r][-1]) for r in range(world)]))
     root = os.environ.get('GRAFT_REPO_ROOT')
     if root and os.path.isdir(os.path.join(root, 'gpurun_out')):
@@ -317,7 +317,7 @@ def test_config5_shape_multi_rank(world, mode):
         _C5S_REF['ref'] = _single_process(p, m0, np.float64, iters)
     model, cg1 = _C5S_REF['ref']
     W0, H0, T0, cg0, same0, _, desc = out[0]['float64']
-    print('config 5 shape, %d ranks, %s: %s' % (world, mode, desc))
+    evidence('config 5 shape, %d ranks, %s: %s' % (world, mode, desc))
     for r in range(1, world):
         W, H, Th, cg = out[r]['float64'][:4]
         assert np.array_equal(W0, W) and np.array_equal(H0, H) and np.array_equal(T0, Th) and cg0 == cg, r

@@ -14,7 +14,7 @@ import pytest
 
 import oracle_py as O
 import trmf
-from helpers import TOL, make_model, relfro, relmax
+from helpers import evidence, TOL, make_model, relfro, relmax
 from trmf import session, synth
 
 pytestmark = pytest.mark.gpu
@@ -34,11 +34,17 @@ def test_config3_full_size_vs_oracle():
     Jo = O.objective(p['Y'], p['lag_set'], W, H, Th, synth.HYPER)
     Jp = O.objective(p['Y'], p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
     cg_o, cg_p = [l['cg_iter'] for l in log], [x['cg_iter'] for x in st]
-    print('c3 full size: J oracle %.10g gpu %.10g rel %.2e; relfro W %.2e H %.2e Th %.2e; CG oracle %s gpu %s' % (
+    evidence('c3 full size: J oracle %.10g gpu %.10g rel %.2e; relfro W %.2e H %.2e Th %.2e; CG oracle %s gpu %s' % (
         Jo, Jp, abs(Jp - Jo) / Jo, relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th), cg_o, cg_p))
     assert abs(Jp - Jo) / Jo < 1e-5
     assert relfro(model.H, H) < 1e-3 and relfro(model.W, W) < 1e-3
     assert all(abs(a - b) <= 1 for a, b in zip(cg_o, cg_p))
+    # the CG's r^T r is the recurrence rho - 2 alpha <r,Hd> + alpha^2 <Hd,Hd> (the reference recomputes r^T r, rf_tron.h:492); the
+    # stop test reads it.  Its drift against the DIRECT norm |-g - H s|^2 of the same step, at the stopping iteration:
+    drift = [abs(x['cg_rnorm'] ** 2 - x['cg_rnorm_direct'] ** 2) / x['cg_rnorm_direct'] ** 2 for x in st if x['cg_rnorm_direct'] > 0]
+    evidence('c3 full size: CG recurrence vs direct residual norm at the stopping step, |rho_rec - rho_direct| / rho_direct per iteration: %s; '
+             'cg_rnorm / cgtol-side |g|: %s' % (['%.1e' % d for d in drift], ['%.4f' % (x['cg_rnorm'] / x['gnorm']) for x in st]))
+    assert drift and max(drift) < 1e-2      # far inside the margin of the eps_cg = 0.1 exit
 
 
 def test_config3_full_size_vs_reference_build():
@@ -71,7 +77,7 @@ def test_config3_full_size_vs_reference_build():
 
     (Wf, Hf, _), mf, _ = both(1, (big, 1, big))                # F-solve only
     (Wx, Hx, _), mx, _ = both(1, (1, big, big))                # X-solve only
-    print('config 3 vs the reference build, one phase from the warm state: F-solve relfro(H) %.2e; X-solve relfro(W) %.2e' % (
+    evidence('config 3 vs the reference build, one phase from the warm state: F-solve relfro(H) %.2e; X-solve relfro(W) %.2e' % (
         relfro(mf.H, Hf), relfro(mx.W, Wx)))
     (W, H, Th), model, st = both(2, (1, 1, 2))
     Wp, Hp, Tp = W0.copy(), H0.copy(), np.asfortranarray(T0.copy())
@@ -80,7 +86,7 @@ def test_config3_full_size_vs_reference_build():
     Jg = O.objective(Y, lags, model.W, model.H, model.lag_val, synth.HYPER)
     Jp = O.objective(Y, lags, Wp, Hp, Tp, synth.HYPER)
     cg_p, cg_g = [l['cg_iter'] for l in log], [x['cg_iter'] for x in st]
-    print('config 3 vs the reference build, 2 iterations from the warm state: J ref %.10g gpu %.10g rel %.2e (restatement vs ref %.2e); '
+    evidence('config 3 vs the reference build, 2 iterations from the warm state: J ref %.10g gpu %.10g rel %.2e (restatement vs ref %.2e); '
           'relfro W %.2e H %.2e Theta %.2e; CG restatement %s gpu %s' % (Jr, Jg, abs(Jg - Jr) / Jr, abs(Jp - Jr) / Jr, relfro(model.W, W),
                                                                         relfro(model.H, H), relfro(model.lag_val, Th), cg_p, cg_g))
     assert abs(Jg - Jr) / Jr < 1e-5
@@ -112,7 +118,7 @@ def test_config5_full_size_single_gpu_vs_oracle():
         s.run(2); st2 = s.stats(2); J3 = s.objective()
     Jo = O.objective(Y, p['lag_set'], W, H, Th, synth.HYPER)
     Jp = O.objective(Y, p['lag_set'], model.W, model.H, model.lag_val, synth.HYPER)
-    print('c5 full size: J oracle %.12g gpu %.12g (device %.12g) rel %.2e; relmax H %.2e W %.2e; CG oracle %s gpu %s; ms F %.2f X %.2f' % (
+    evidence('c5 full size: J oracle %.12g gpu %.12g (device %.12g) rel %.2e; relmax H %.2e W %.2e; CG oracle %s gpu %s; ms F %.2f X %.2f' % (
         Jo, Jp, Jdev, abs(Jp - Jo) / Jo, relmax(model.H, H), relmax(model.W, W), [l['cg_iter'] for l in log],
         [x['cg_iter'] for x in st], st[0]['ms_F'], st[0]['ms_X']))
     assert relmax(model.H, H) < 1e-6 and relmax(model.W, W) < 1e-6
