@@ -1,0 +1,127 @@
+// generic_kernels.hpp -- the observed-entries path for ranks the register-tiled kernels do not cover (64 < k <= 256).
+//
+// The reference allocates a k x k scratch per thread for ANY k (trmf.cpp:362-365) and a grid search over the rank
+// (python/trmf/trmf.py:331-346) may well walk past 64; the drop-in must compute there, not answer "[ERR MSG]" (VERDICT r3).
+// These kernels are deliberately plain -- one workgroup per row, the k x k system accumulated in (L2-resident) global scratch,
+// a workgroup-wide Cholesky -- and slow next to gram_kernels.hpp; they exist for coverage, not for the roofline.  Same
+// arithmetic as the reference where it prescribes one: the Gram and the right-hand side accumulate in val_type, one observed
+// entry after the other in CSR order (trmf.cpp:382-389: fused multiply-adds), upper triangle mirrored, lambda added to the
+// diagonal afterwards (:390-394), posv('U') (rf_matrix.h:3008-3014) as a right-looking Cholesky + two substitutions.
+// The X-solve of such ranks runs the unfused CG (ar_tile_kernel + apply_kernel<false>, any KP) on the Grams built here.
+#pragma once
+
+#include "cg_kernels.hpp"
+
+namespace trmf {
+
+constexpr int kMaxRankGeneric = 256;     // apply_kernel: one thread per (timestamp, column)
+constexpr int kGenChunk = 8;             // observed entries staged per pass
+constexpr int kGenBlocks = 512;          // workgroups (and k x k scratch slots) of the F-solve
+
+// SOLVE = true : F-solve of item rows [row_begin, row_end): h_i = (sum x x^T + lambda I)^-1 sum y x; empty rows untouched
+//                (trmf.cpp:374).  `A` = scratch, (k*k) reals per workgroup; `out` = H (rows x KP, column-interleaved).
+// SOLVE = false: X-side cache of timestamps [row_begin, row_end): G_i = sum h h^T (full k x k, `gs` elements apart) into `A`,
+//                b_i = sum y h into `out` = Bv (logical column order).
+template <bool SOLVE>
+__global__ __launch_bounds__(256) void gram_generic_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                                           const real *__restrict__ val, const real *__restrict__ X,
+                                                           uint32_t row_begin, uint32_t row_end, int k, int KP, int NT,
+                                                           real lambda, real *__restrict__ A_base, size_t gs,
+                                                           real *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char gen_smem[];
+    real *xs = reinterpret_cast<real *>(gen_smem);          // [kGenChunk][k] gathered factor rows, logical column order
+    real *ys = xs + (size_t)kGenChunk * k;                    // [kGenChunk] observation values
+    real *bl = ys + kGenChunk;                                // [k] right-hand side / solution
+    const int tid = threadIdx.x;
+    for (uint32_t row = row_begin + blockIdx.x; row < row_end; row += gridDim.x) {
+        const uint32_t p0 = ptr[row], p1 = ptr[row + 1];
+        if (SOLVE && p1 == p0) continue;                      // uniform: no observation of this item
+        real *A = SOLVE ? A_base + (size_t)blockIdx.x * k * k : A_base + (size_t)row * gs;
+        for (int e = tid; e < k * k; e += 256) A[e] = 0;
+        for (int t = tid; t < k; t += 256) bl[t] = 0;
+        __syncthreads();
+        for (uint32_t c0 = p0; c0 < p1; c0 += kGenChunk) {
+            const int cnt = (int)min((uint32_t)kGenChunk, p1 - c0);
+            for (int e = tid; e < cnt * k; e += 256) {
+                const int c = e / k, t = e - c * k;
+                xs[c * k + t] = X[(size_t)idx[c0 + c] * KP + colpos(t, NT)];
+            }
+            if (tid < cnt) ys[tid] = val[c0 + tid];
+            __syncthreads();
+            for (int e = tid; e < k * k; e += 256) {          // upper triangle, entry by entry in CSR order
+                const int a = e / k, b = e - a * k;
+                if (a > b) continue;
+                real acc = A[e];
+                for (int c = 0; c < cnt; c++) acc = fma(xs[c * k + a], xs[c * k + b], acc);
+                A[e] = acc;
+            }
+            for (int t = tid; t < k; t += 256) {
+                real acc = bl[t];
+                for (int c = 0; c < cnt; c++) acc = fma(ys[c], xs[c * k + t], acc);
+                bl[t] = acc;
+            }
+            __syncthreads();
+        }
+        if (!SOLVE) {
+            for (int e = tid; e < k * k; e += 256) {          // mirror
+                const int a = e / k, b = e - a * k;
+                if (a > b) A[e] = A[b * k + a];
+            }
+            for (int t = tid; t < k; t += 256) out[(size_t)row * KP + t] = bl[t];
+            __syncthreads();
+            continue;
+        }
+        for (int t = tid; t < k; t += 256) A[t * k + t] += lambda;
+        __syncthreads();
+        // upper Cholesky A = U^T U in place (right-looking, one column per thread), then U^T z = b, U x = z
+        for (int j = 0; j < k; j++) {
+            const real ajj = sqrt(A[j * k + j]);
+            __syncthreads();
+            for (int c = j + tid; c < k; c += 256) A[j * k + c] = (c == j) ? ajj : A[j * k + c] / ajj;
+            __syncthreads();
+            for (int c = j + 1 + tid; c < k; c += 256) {
+                const real ujc = A[j * k + c];
+                for (int s = j + 1; s <= c; s++) A[s * k + c] -= A[j * k + s] * ujc;
+            }
+            __syncthreads();
+        }
+        for (int q = 0; q < k; q++) {
+            if (tid == 0) bl[q] = bl[q] / A[q * k + q];
+            __syncthreads();
+            for (int i = q + 1 + tid; i < k; i += 256) bl[i] -= A[q * k + i] * bl[q];
+            __syncthreads();
+        }
+        for (int q = k - 1; q >= 0; q--) {
+            if (tid == 0) bl[q] = bl[q] / A[q * k + q];
+            __syncthreads();
+            for (int i = tid; i < q; i += 256) bl[i] -= A[i * k + q] * bl[q];
+            __syncthreads();
+        }
+        for (int t = tid; t < k; t += 256) out[(size_t)row * KP + colpos(t, NT)] = bl[t];
+        __syncthreads();
+    }
+}
+inline size_t gram_generic_lds(int k) { return ((size_t)kGenChunk * k + kGenChunk + k) * sizeof(real); }
+
+// squared residuals of one timestamp row (trmf_session_objective): sum (y - w.h)^2, products in val_type, sum in double
+__global__ __launch_bounds__(256) void loss_generic_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                                           const real *__restrict__ val, const real *__restrict__ Hf,
+                                                           const real *__restrict__ W, double *__restrict__ lossrow,
+                                                           uint32_t row_begin, uint32_t row_end, int KP) {
+    __shared__ double smem[256];
+    const uint32_t row = row_begin + blockIdx.x;
+    if (row >= row_end) return;
+    const real *w = W + (size_t)row * KP;
+    double l = 0;
+    for (uint32_t e = ptr[row] + threadIdx.x; e < ptr[row + 1]; e += 256) {
+        const real *h = Hf + (size_t)idx[e] * KP;
+        real dot = 0;
+        for (int t = 0; t < KP; t++) dot = fma(w[t], h[t], dot);             // pad columns are zero on both sides
+        const double r = (double)val[e] - (double)dot;
+        l += r * r;
+    }
+    l = block_allsum(l, smem);
+    if (threadIdx.x == 0) lossrow[row] = l;
+}
+
+}  // namespace trmf

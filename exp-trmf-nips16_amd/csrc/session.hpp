@@ -26,6 +26,7 @@
 #include "cg_persist.hpp"
 #include "comm.hpp"
 #include "full_kernels.hpp"
+#include "generic_kernels.hpp"
 #include "common.hpp"
 #include "gram_kernels.hpp"
 #include "resident_kernels.hpp"
@@ -119,6 +120,8 @@ struct TrmfSessionImpl {
     std::vector<PhaseEvents> events;
     static constexpr int kEventRing = 64;
     int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
+    bool generic = false;                     // 64 < k <= 256: generic_kernels.hpp for the Grams / the F-solve, unfused CG
+    DevBuf<real> gen_scratch, theta_scratch;  // k x k systems of the generic F-solve; |L| x |L| systems of long lag sets
     bool gpacked = false;                     // unfused path: G holds upper triangles (packed_gram_elems(k) per timestamp), apply_kernel<true>
     int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), tiles of the problem
     // fused path: per-tile records of each launch (cg_kernels.hpp "per-tile partial records") in three message buffers:
@@ -345,6 +348,7 @@ struct TrmfSessionImpl {
                const PyMatrix *Hm, const PyMatrix *LVm) {
         T = (int)Y->rows; n = (int)Y->cols; k = (int)Wm->cols; nnz = Y->nnz;
         KP = padded_rank(k); NT = KP / kTile; KMAX = ((k + 7) / 8) * 8;
+        generic = k > kMaxRank;
         nlag = (int)lag_size; midx = nlag ? (int)lags[nlag - 1] : 0;
         comm = active_comm();
         if (const char *e = getenv("TRMF_FSOLVE")) {
@@ -454,9 +458,15 @@ struct TrmfSessionImpl {
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
         const int npairs = nlag * (nlag + 1) / 2 + nlag;
         if (theta_part.alloc((size_t)k * nchunk * std::max(npairs, 1))) return kFail;
-        if (nlag && (allow_dyn_lds(theta_gram_kernel, theta_gram_lds(), "Theta Gram (max lag too large)") ||
-                     allow_dyn_lds(theta_solve_kernel, theta_solve_lds(), "Theta solve (too many lags)")))
-            return kFail;
+        if (nlag && allow_dyn_lds(theta_gram_kernel, theta_gram_lds(), "Theta Gram (max lag too large)")) return kFail;
+        if (nlag && theta_solve_lds() > kLdsMax) {          // long lag sets: the |L| x |L| systems in global scratch
+            if (theta_scratch.alloc((size_t)k * ((size_t)nlag * nlag + nlag), false)) return kFail;
+        } else if (nlag && allow_dyn_lds(theta_solve_kernel, theta_solve_lds(), "Theta solve (too many lags)")) return kFail;
+        if (generic) {
+            if (gen_scratch.alloc((size_t)kGenBlocks * k * k, false)) return kFail;
+            if (allow_dyn_lds(gram_generic_kernel<true>, gram_generic_lds(k), "generic F-solve") ||
+                allow_dyn_lds(gram_generic_kernel<false>, gram_generic_lds(k), "generic Gram build")) return kFail;
+        }
 
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
@@ -480,14 +490,14 @@ struct TrmfSessionImpl {
             if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
             // the tile kernel addresses the CG vectors with 32-bit byte offsets through buffer descriptors
             const bool fits32 = (uint64_t)(T + 1) * KP * sizeof(real) < 0x7fffffffull;
-            if (fits32 && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
+            if (!generic && fits32 && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
                 tile_TI = TI;
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
         }
         // The cached Grams: k x k per timestamp for the fused kernel; the unfused path's product streams them once per CG
         // step and nothing else (1.64 GB per step at config 5), so there only the upper triangle is kept (packed_gram_elems)
-        gpacked = !full && tile_TI == 0 && !getenv("TRMF_GRAM_FULL");
+        gpacked = !full && !generic && tile_TI == 0 && !getenv("TRMF_GRAM_FULL");
         const size_t gelems = gpacked ? packed_gram_elems(k) : (size_t)k * k;
         if (G.alloc((full ? 1 : (size_t)T * gelems) + kHvGramPad)) return kFail;
         if (gpacked) {
@@ -809,6 +819,12 @@ struct TrmfSessionImpl {
     DevBuf<double> gramx_times;
     int dbg_flags = 0;           // TRMF_DEBUG_ABLATE: bit0 skip Gram, bit1 skip factorisation, bit2 skip back-solve
     int launch_fsolve_rows(uint32_t rb, uint32_t re) {
+        if (generic) {
+            if (re > rb)
+                hipLaunchKernelGGL(gram_generic_kernel<true>, dim3(std::min<uint32_t>(kGenBlocks, re - rb)), dim3(256), gram_generic_lds(k), stream,
+                                   Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, rb, re, k, KP, NT, (real)lambdaI, gen_scratch.p, (size_t)0, H.p);
+            return 0;
+        }
 #define TRMF_FSOLVE_SWITCH(FN)                                                       \
         switch (KMAX) {                                                              \
             case 8:  FN<1, 8>(rb, re); break;                                        \
@@ -963,6 +979,20 @@ struct TrmfSessionImpl {
         }
 #undef TRMF_LAUNCH_GRAM_X
     }
+    void launch_gram_x_rows(uint32_t rb, uint32_t re) {
+        if (generic) {
+            if (re > rb)
+                hipLaunchKernelGGL(gram_generic_kernel<false>, dim3(std::min<uint32_t>(4096, re - rb)), dim3(256), gram_generic_lds(k), stream,
+                                   Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, rb, re, k, KP, NT, real(0), G.p, xp.gstride, Bv.p);
+            return;
+        }
+        switch (NT) {
+            case 1: launch_gram_x<1>(rb, re); break;
+            case 2: launch_gram_x<2>(rb, re); break;
+            case 3: launch_gram_x<3>(rb, re); break;
+            default: launch_gram_x<4>(rb, re); break;
+        }
+    }
     template <int NT_> void launch_loss(const real *Wv, uint32_t rb, uint32_t re) {
         if (re > rb)
             hipLaunchKernelGGL((loss_kernel<NT_>), dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p,
@@ -971,12 +1001,7 @@ struct TrmfSessionImpl {
     int gram_x(bool timeshard = false) {
         if (timeshard || uts) {     // time-sharded CG: a rank only ever reads the Grams / right-hand sides of its own timestamps
             const uint32_t rb = (uint32_t)(uts ? ush.row_b : tsh_rank.row_b), re = (uint32_t)(uts ? ush.row_e : tsh_rank.row_e);
-            switch (NT) {
-                case 1: launch_gram_x<1>(rb, re); break;
-                case 2: launch_gram_x<2>(rb, re); break;
-                case 3: launch_gram_x<3>(rb, re); break;
-                default: launch_gram_x<4>(rb, re); break;
-            }
+            launch_gram_x_rows(rb, re);
             TRMF_HIP_CHECK(hipGetLastError());
             return 0;
         }
@@ -986,12 +1011,7 @@ struct TrmfSessionImpl {
         const uint32_t rb = replicate ? 0u : (uint32_t)xbounds[comm->rank];
         const uint32_t re = replicate ? (uint32_t)T : (uint32_t)xbounds[comm->rank + 1];
         if (measure) TRMF_HIP_CHECK(hipEventRecord(gx0, stream));
-        switch (NT) {
-            case 1: launch_gram_x<1>(rb, re); break;
-            case 2: launch_gram_x<2>(rb, re); break;
-            case 3: launch_gram_x<3>(rb, re); break;
-            default: launch_gram_x<4>(rb, re); break;
-        }
+        launch_gram_x_rows(rb, re);
         TRMF_HIP_CHECK(hipGetLastError());
         gramx_calls++;
         if (replicate) return 0;                                    // every rank built every row: nothing to gather
@@ -1013,6 +1033,9 @@ struct TrmfSessionImpl {
     int loss(const real *Wv, bool all_rows) {
         const uint32_t rb = all_rows ? 0u : (uint32_t)xbounds[comm->rank];
         const uint32_t re = all_rows ? (uint32_t)T : (uint32_t)xbounds[comm->rank + 1];
+        if (generic) {
+            if (re > rb) hipLaunchKernelGGL(loss_generic_kernel, dim3(re - rb), dim3(256), 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, Wv, lossrow.p, rb, re, KP);
+        } else
         switch (NT) {
             case 1: launch_loss<1>(Wv, rb, re); break;
             case 2: launch_loss<2>(Wv, rb, re); break;
@@ -1617,9 +1640,9 @@ struct TrmfSessionImpl {
         const size_t lds1 = theta_gram_lds();
         hipLaunchKernelGGL(theta_gram_kernel, dim3(k, nchunk), dim3(256), lds1, stream, W.p, T, KP, lag_set.p,
                            nlag, midx, npairs, theta_part.p);
-        const size_t lds2 = theta_solve_lds();
+        const size_t lds2 = theta_scratch.p ? 0 : theta_solve_lds();
         hipLaunchKernelGGL(theta_solve_kernel, dim3(k), dim3(256), lds2, stream, theta_part.p, nchunk, nlag,
-                           npairs, lambdaLag, theta.p);
+                           npairs, lambdaLag, theta.p, theta_scratch.p);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1686,7 +1709,8 @@ struct TrmfSessionImpl {
     std::string describe() const {
         char buf[640];
         if (comm->world <= 1) {
-            snprintf(buf, sizeof buf, "1 rank; X-solve %s", tile_TI <= 0 ? "unfused (AR tile + cached-Gram product per CG step)"
+            snprintf(buf, sizeof buf, "1 rank; X-solve %s", generic ? "unfused; generic kernels for rank > 64 (Gram build, F-solve)"
+                     : tile_TI <= 0 ? "unfused (AR tile + cached-Gram product per CG step)"
                      : persist_state == 1 ? "fused, one persistent kernel per solve" : persist_state == 0 ? "fused (not run yet)" : "fused, one launch per CG step");
             return buf;
         }

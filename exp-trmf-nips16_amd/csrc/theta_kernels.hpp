@@ -11,7 +11,7 @@
 namespace trmf {
 
 constexpr int kThetaChunk = 512;    // timestamps per workgroup of theta_gram_kernel (2048 -> 512: 92 us -> ~40 us at config 3)
-constexpr int kMaxLags = 128;
+constexpr int kMaxLags = 1024;      // beyond ~140 (fp64) / 200 (fp32) lags the |L| x |L| systems of theta_solve_kernel no longer fit LDS: global scratch
 
 // pair index p in [0, npairs): p < nlag -> rhs entry y[p] = <s_i, s_{i-L_p}>;
 // otherwise the upper-triangle entry (a, b), a <= b, in row-major order.
@@ -146,11 +146,13 @@ __global__ __launch_bounds__(256) void theta_gram_kernel(const real *__restrict_
 // one workgroup per latent dimension; dynamic LDS = (nlag*nlag + nlag) * sizeof(real).  All 256 threads add up the
 // time-chunk partials (a single wavefront streaming nchunk * npairs doubles is latency-bound: 125 us of the former
 // 187 us at 48 lags); the |L| x |L| solve itself is one wavefront's work, the other three retire after the sum.
+// `scratch` != null: the systems live there ((nlag*nlag + nlag) reals per latent dimension, L2-resident) instead of LDS -- lag sets
+// too long for LDS (the reference has no limit on |L|: trmf.cpp:425-484); same code, workgroup barriers order the accesses.
 __global__ __launch_bounds__(256) void theta_solve_kernel(const double *__restrict__ part, int nchunk,
                                                          int nlag, int npairs, double lambdaLag,
-                                                         real *__restrict__ theta) {
+                                                         real *__restrict__ theta, real *__restrict__ scratch) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    real *A = reinterpret_cast<real *>(smem_raw);       // nlag x nlag, element (i,j) at A[i*nlag+j]
+    real *A = scratch ? scratch + (size_t)blockIdx.x * ((size_t)nlag * nlag + nlag) : reinterpret_cast<real *>(smem_raw);   // nlag x nlag, (i,j) at A[i*nlag+j]
     real *y = A + nlag * nlag;
     const int t = blockIdx.x, lane = threadIdx.x;
     for (int p = threadIdx.x; p < npairs; p += 256) {

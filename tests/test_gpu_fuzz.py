@@ -120,3 +120,60 @@ def test_unfused_ar_tile_layouts(dtype, T, lags, k, ar_ti, missing, monkeypatch)
     fac = TOL[np.dtype(dtype).name]['factor']
     print('T=%d lags=%s k=%d TI=%s %s: relfro W %.1e H %.1e Th %.1e' % (T, lags, k, ar_ti, np.dtype(dtype).name, relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th)))
     assert relfro(model.W, W) < fac and relfro(model.H, H) < fac and relfro(model.lag_val, Th) < 10 * fac
+
+
+@pytest.mark.parametrize('dtype,k,nlag,T,n', [
+    (np.float64, 65, 5, 300, 120),        # one past the register-tiled kernels
+    (np.float32, 80, 8, 260, 150),
+    (np.float64, 128, 3, 200, 90),
+    (np.float32, 200, 4, 240, 70),
+    (np.float64, 256, 2, 150, 40),        # the generic path's own ceiling (one thread per column in apply_kernel)
+    (np.float64, 8, 160, 700, 60),        # |L| = 160: the |L| x |L| Theta systems no longer fit LDS in fp64
+    (np.float32, 80, 160, 600, 50),       # both at once
+    (np.float32, 12, 230, 900, 40),       # past the fp32 LDS limit as well
+])
+def test_ranks_and_lag_sets_beyond_the_tiled_kernels(dtype, k, nlag, T, n):
+    """the reference computes for any rank (k x k scratch per thread, trmf.cpp:362-365) and any lag set
+    (trmf.cpp:79-147, 425-484); up to round 3 the drop-in answered `[ERR MSG]` above k = 64 or 128 lags.  Ranks 65..256 run the
+    generic kernels (csrc/generic_kernels.hpp) + the unfused CG, long lag sets keep the Theta systems in global scratch.
+    Two ALS iterations against the restatement at the SURVEY.md 8(d) gates."""
+    rng = np.random.RandomState(77 + k + nlag)
+    d = trmf.Model.syn_gen(T, n, 6, [1, 2], seed=k, dtype=np.float64)
+    Yd = d['Y'] + 0.05 * rng.randn(T, n)
+    mask = rng.rand(T, n) < 0.5
+    mask[rng.randint(T)] = False
+    mask[:, rng.randint(n)] = False
+    Y = smat.csr_matrix(np.where(mask, Yd, 0.0).astype(dtype))
+    Y.eliminate_zeros()
+    lags = np.arange(1, nlag + 1, dtype=np.uint32)
+    hyper = dict(lambdaI=0.5, lambdaAR=50.0, lambdaLag=0.5)
+    m0 = trmf.Model.initialize(Y, lags, k, seed=3, dtype=dtype)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    log = O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=2, missing=True, threads=4)
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    with trmf.session.Session(Y, model, missing=True, **hyper) as s:
+        s.run(2); st = s.stats(2); s.download(); desc = s.describe()
+    tol = TOL[np.dtype(dtype).name]
+    print('k=%d |L|=%d %s (%s): relfro W %.1e H %.1e Th %.1e; CG %s vs %s' % (k, nlag, np.dtype(dtype).name, desc, relfro(model.W, W), relfro(model.H, H),
+                                                                      relfro(model.lag_val, Th), [x['cg_iter'] for x in st], [l['cg_iter'] for l in log]))
+    assert np.all(np.isfinite(model.W)) and np.all(np.isfinite(model.H)) and np.all(np.isfinite(model.lag_val))
+    assert relfro(model.W, W) < tol['factor'] and relfro(model.H, H) < tol['factor'] and relfro(model.lag_val, Th) < 10 * tol['factor']
+    assert all(abs(a['cg_iter'] - b['cg_iter']) <= 1 for a, b in zip(st, log))
+    assert ('generic' in desc) == (k > 64)
+
+
+def test_limits_that_remain_are_reported(capfd):
+    """What the drop-in still refuses, loudly and without touching the outputs: a rank above 256 (observed-entries path) or
+    above 64 on the full-observation path, more than 1024 lags."""
+    rng = np.random.RandomState(0)
+    T, n = 60, 30
+    Yd = rng.randn(T, n)
+    for k, nlag, missing, what in ((257, 2, True, 'rank k=257'), (65, 2, False, 'rank k=65'), (4, 1025, True, '|lag_set|=1025')):
+        Y = smat.csr_matrix(Yd) if missing else Yd
+        lags = np.arange(1, nlag + 1, dtype=np.uint32) if nlag < T else np.arange(nlag, dtype=np.uint32)
+        m = trmf.Model.initialize(Y, lags, k, seed=0, dtype=np.float64)
+        W0 = m.W.copy()
+        trmf.train(Y, m, max_iter=1, missing=missing, lambdaI=0.5, lambdaAR=1.0, lambdaLag=0.5)
+        err = capfd.readouterr().err
+        assert '[ERR MSG]' in err and what in err, err
+        assert np.array_equal(m.W, W0)
