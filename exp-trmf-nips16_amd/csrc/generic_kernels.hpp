@@ -14,7 +14,8 @@
 
 namespace trmf {
 
-constexpr int kMaxRankGeneric = 256;     // apply_kernel: one thread per (timestamp, column)
+constexpr int kMaxRankGeneric = 1024;    // the k x k scratch slots and the 160 KB of LDS bound it, nothing else does
+constexpr int kApplyThreadPerColumn = 256;   // apply_kernel: one thread per (timestamp, column) up to here, apply_wide_kernel beyond
 constexpr int kGenChunk = 8;             // observed entries staged per pass
 constexpr int kGenBlocks = 512;          // workgroups (and k x k scratch slots) of the F-solve
 
@@ -102,6 +103,56 @@ __global__ __launch_bounds__(256) void gram_generic_kernel(const uint32_t *__res
     }
 }
 inline size_t gram_generic_lds(int k) { return ((size_t)kGenChunk * k + kGenChunk + k) * sizeof(real); }
+
+// out = base + G_i v (- b_i) for ranks above 256 (apply_kernel gives a thread to every column of a timestamp): one workgroup per
+// timestamp (grid-stride), the operand row in LDS, a thread walks columns t, t + 256, ...  Same interface, same products in the
+// same order s = 0 .. k-1, same partial-sum slots as apply_kernel<false>.
+__global__ __launch_bounds__(256) void apply_wide_kernel(XParams p, const XState *__restrict__ st, int cg_it,
+                                                         const real *__restrict__ v, const real *__restrict__ rvec,
+                                                         const real *__restrict__ base, const real *__restrict__ G,
+                                                         const real *__restrict__ Bv, int minus_b, real *__restrict__ out, int dot_mode,
+                                                         double *__restrict__ Pdot, int row0, int nrows, int slot0) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wide_smem[];
+    __shared__ double smem[256];
+    real *vs = reinterpret_cast<real *>(wide_smem);          // [k] operand row, logical column order
+    const bool cg = cg_it >= 0;
+    if (cg && st->stop_it <= cg_it) return;
+    const int k = p.k, KP = p.KP, NT = p.NT;
+    double dot = 0, lq = 0, rhd = 0, hh = 0;
+    for (int r = blockIdx.x; r < nrows; r += gridDim.x) {
+        const int i = row0 + r;
+        __syncthreads();
+        for (int t = threadIdx.x; t < k; t += 256) vs[t] = v[(size_t)i * KP + colpos(t, NT)];
+        __syncthreads();
+        const real *Gi = G + (size_t)i * p.gstride;
+        for (int t = threadIdx.x; t < k; t += 256) {
+            const int tp = colpos(t, NT);
+            double acc = 0;
+            for (int s = 0; s < k; s++) acc += (double)Gi[(size_t)s * k + t] * (double)vs[s];
+            const real x = vs[t];
+            if (minus_b) {
+                const double bb = (double)Bv[(size_t)i * KP + t];
+                lq += (double)x * (acc - 2.0 * bb);
+                acc -= bb;
+            }
+            const real o = (real)((double)base[(size_t)i * KP + tp] + acc);
+            out[(size_t)i * KP + tp] = o;
+            dot += (double)(dot_mode ? x : o) * (double)o;
+            if (cg) { rhd += (double)rvec[(size_t)i * KP + tp] * (double)o; hh += (double)o * (double)o; }
+        }
+    }
+    if (cg) {
+        block_allsum3(dot, rhd, hh, smem);
+        if (threadIdx.x == 0) {
+            double *Po = Pdot + (size_t)(P_CG0 - P_DOT + 3 * (cg_it & 1)) * p.pstride + slot0 + blockIdx.x;
+            Po[0] = dot; Po[(size_t)p.pstride] = rhd; Po[2 * (size_t)p.pstride] = hh;
+        }
+        return;
+    }
+    dot = block_allsum(dot, smem);
+    lq = block_allsum(lq, smem);
+    if (threadIdx.x == 0) { Pdot[slot0 + blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + slot0 + blockIdx.x] = lq; }
+}
 
 // squared residuals of one timestamp row (trmf_session_objective): sum (y - w.h)^2, products in val_type, sum in double
 __global__ __launch_bounds__(256) void loss_generic_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,

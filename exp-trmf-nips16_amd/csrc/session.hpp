@@ -1476,6 +1476,11 @@ struct TrmfSessionImpl {
         // shared Gram, or the packed Grams of one row group, staged per workgroup
         const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : gpacked ? (size_t)apply_stages(k) * 512 * sizeof(real) : 0;
         auto launch_apply = [&](int blocks, int row_b, int rows, int slot_b) {
+            if (k > kApplyThreadPerColumn) {       // very wide ranks: a workgroup per timestamp walks the columns
+                hipLaunchKernelGGL(apply_wide_kernel, dim3(blocks), dim3(256), (size_t)k * sizeof(real), stream, xp, st, cg_it, operand, resid, arbase.p,
+                                   Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), row_b, rows, slot_b);
+                return;
+            }
 #define TRMF_LAUNCH_APPLY_PACKED(NS)                                                                                          \
     hipLaunchKernelGGL((apply_kernel<true, NS>), dim3(blocks), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p, \
                        Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, row_b, rows, slot_b)

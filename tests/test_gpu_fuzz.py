@@ -127,14 +127,16 @@ def test_unfused_ar_tile_layouts(dtype, T, lags, k, ar_ti, missing, monkeypatch)
     (np.float32, 80, 8, 260, 150),
     (np.float64, 128, 3, 200, 90),
     (np.float32, 200, 4, 240, 70),
-    (np.float64, 256, 2, 150, 40),        # the generic path's own ceiling (one thread per column in apply_kernel)
+    (np.float64, 256, 2, 150, 40),        # the last rank with one thread per column in apply_kernel
+    (np.float32, 300, 2, 120, 30),        # apply_wide_kernel
+    (np.float64, 520, 1, 90, 24),
     (np.float64, 8, 160, 700, 60),        # |L| = 160: the |L| x |L| Theta systems no longer fit LDS in fp64
     (np.float32, 80, 160, 600, 50),       # both at once
     (np.float32, 12, 230, 900, 40),       # past the fp32 LDS limit as well
 ])
 def test_ranks_and_lag_sets_beyond_the_tiled_kernels(dtype, k, nlag, T, n):
     """the reference computes for any rank (k x k scratch per thread, trmf.cpp:362-365) and any lag set
-    (trmf.cpp:79-147, 425-484); up to round 3 the drop-in answered `[ERR MSG]` above k = 64 or 128 lags.  Ranks 65..256 run the
+    (trmf.cpp:79-147, 425-484); up to round 3 the drop-in answered `[ERR MSG]` above k = 64 or 128 lags.  Ranks 65..1024 run the
     generic kernels (csrc/generic_kernels.hpp) + the unfused CG, long lag sets keep the Theta systems in global scratch.
     Two ALS iterations against the restatement at the SURVEY.md 8(d) gates."""
     rng = np.random.RandomState(77 + k + nlag)
@@ -163,12 +165,12 @@ def test_ranks_and_lag_sets_beyond_the_tiled_kernels(dtype, k, nlag, T, n):
 
 
 def test_limits_that_remain_are_reported(capfd):
-    """What the drop-in still refuses, loudly and without touching the outputs: a rank above 256 (observed-entries path) or
+    """What the drop-in still refuses, loudly and without touching the outputs: a rank above 1024 (observed-entries path) or
     above 64 on the full-observation path, more than 1024 lags."""
     rng = np.random.RandomState(0)
     T, n = 60, 30
     Yd = rng.randn(T, n)
-    for k, nlag, missing, what in ((257, 2, True, 'rank k=257'), (65, 2, False, 'rank k=65'), (4, 1025, True, '|lag_set|=1025')):
+    for k, nlag, missing, what in ((1025, 2, True, 'rank k=1025'), (65, 2, False, 'rank k=65'), (4, 1025, True, '|lag_set|=1025')):
         Y = smat.csr_matrix(Yd) if missing else Yd
         lags = np.arange(1, nlag + 1, dtype=np.uint32) if nlag < T else np.arange(nlag, dtype=np.uint32)
         m = trmf.Model.initialize(Y, lags, k, seed=0, dtype=np.float64)
