@@ -1,4 +1,4 @@
-// generic_kernels.hpp -- the observed-entries path for ranks the register-tiled kernels do not cover (64 < k <= 256).
+// generic_kernels.hpp -- both training paths for ranks the register-tiled kernels do not cover (64 < k <= 1024).
 //
 // The reference allocates a k x k scratch per thread for ANY k (trmf.cpp:362-365) and a grid search over the rank
 // (python/trmf/trmf.py:331-346) may well walk past 64; the drop-in must compute there, not answer "[ERR MSG]" (VERDICT r3).
@@ -152,6 +152,90 @@ __global__ __launch_bounds__(256) void apply_wide_kernel(XParams p, const XState
     dot = block_allsum(dot, smem);
     lq = block_allsum(lq, smem);
     if (threadIdx.x == 0) { Pdot[slot0 + blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + slot0 + blockIdx.x] = lq; }
+}
+
+// ---- full-observation path (missing == 0; trmf.cpp:299-351, 155-215) for ranks above 64 -------------------------------------------
+// out[row][t] = sum_e val[e] * X[idx[e]][t]   (sparse Y times a factor; `out` rows x KP in LOGICAL column order like spmm_rows_kernel's;
+// val_type multiply-adds in entry order: the reference's gmat_x_dmat loop)
+__global__ __launch_bounds__(256) void spmm_generic_kernel(const uint32_t *__restrict__ ptr, const uint32_t *__restrict__ idx,
+                                                           const real *__restrict__ val, const real *__restrict__ X, real *__restrict__ out,
+                                                           uint32_t row_begin, uint32_t row_end, int k, int KP, int NT) {
+    for (uint32_t row = row_begin + blockIdx.x; row < row_end; row += gridDim.x) {
+        const uint32_t p0 = ptr[row], p1 = ptr[row + 1];
+        for (int t = threadIdx.x; t < k; t += 256) {
+            const int tp = colpos(t, NT);
+            real acc = 0;
+            for (uint32_t e = p0; e < p1; e++) acc = fma(val[e], X[(size_t)idx[e] * KP + tp], acc);
+            out[(size_t)row * KP + t] = acc;
+        }
+    }
+}
+// C[m][t] = sum_j A[j][m] * B[j][t]   (dense A: K x M row-major, B: K x KP factor; the reference's gemm, rf_matrix.h:3182-3216;
+// products widened, sum in double, rounded once)
+__global__ __launch_bounds__(256) void dense_tn_generic_kernel(const real *__restrict__ A, int K, int M, const real *__restrict__ B,
+                                                               real *__restrict__ out, int k, int KP, int NT) {
+    for (int m = blockIdx.x; m < M; m += gridDim.x)
+        for (int t = threadIdx.x; t < k; t += 256) {
+            const int tp = colpos(t, NT);
+            double acc = 0;
+            for (int j = 0; j < K; j++) acc += (double)A[(size_t)j * M + m] * (double)B[(size_t)j * KP + tp];
+            out[(size_t)m * KP + t] = (real)acc;
+        }
+}
+// GS = A^T A (+ lambda on the diagonal, trmf.cpp:322-324): workgroup a, thread b
+__global__ __launch_bounds__(256) void small_gram_generic_kernel(const real *__restrict__ A, int rows, int k, int KP, int NT, real lambda,
+                                                                 real *__restrict__ GS) {
+    const int a = blockIdx.x, ap = colpos(a, NT);
+    for (int b = threadIdx.x; b < k; b += 256) {
+        const int bp = colpos(b, NT);
+        double acc = 0;
+        for (int r = 0; r < rows; r++) acc += (double)A[(size_t)r * KP + ap] * (double)A[(size_t)r * KP + bp];
+        real v = (real)acc;
+        if (a == b) v += lambda;
+        GS[(size_t)a * k + b] = v;
+    }
+}
+// upper Cholesky of ONE k x k matrix in global memory (posv 'U' of trmf.cpp:333), one workgroup
+__global__ __launch_bounds__(256) void chol_generic_kernel(const real *__restrict__ GS, real *__restrict__ U, int k) {
+    const int tid = threadIdx.x;
+    for (int e = tid; e < k * k; e += 256) U[e] = GS[e];
+    __syncthreads();
+    for (int j = 0; j < k; j++) {
+        const real ajj = sqrt(U[j * k + j]);
+        __syncthreads();
+        for (int c = j + tid; c < k; c += 256) U[j * k + c] = (c == j) ? ajj : U[j * k + c] / ajj;
+        __syncthreads();
+        for (int c = j + 1 + tid; c < k; c += 256) {
+            const real ujc = U[j * k + c];
+            for (int s = j + 1; s <= c; s++) U[s * k + c] -= U[j * k + s] * ujc;
+        }
+        __syncthreads();
+    }
+}
+// H[i][:] = (U^T U)^-1 b_i: a workgroup per right-hand side (grid-stride), unknowns in LDS, column-oriented substitutions
+__global__ __launch_bounds__(256) void solve_rows_generic_kernel(const real *__restrict__ U, const real *__restrict__ Brows, real *__restrict__ out,
+                                                                 int rows, int k, int KP, int NT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sr_smem[];
+    real *x = reinterpret_cast<real *>(sr_smem);
+    const int tid = threadIdx.x;
+    for (int i = blockIdx.x; i < rows; i += gridDim.x) {
+        __syncthreads();
+        for (int t = tid; t < k; t += 256) x[t] = Brows[(size_t)i * KP + t];
+        __syncthreads();
+        for (int q = 0; q < k; q++) {
+            if (tid == 0) x[q] = x[q] / U[q * k + q];
+            __syncthreads();
+            for (int r = q + 1 + tid; r < k; r += 256) x[r] -= U[q * k + r] * x[q];
+            __syncthreads();
+        }
+        for (int q = k - 1; q >= 0; q--) {
+            if (tid == 0) x[q] = x[q] / U[q * k + q];
+            __syncthreads();
+            for (int r = tid; r < q; r += 256) x[r] -= U[r * k + q] * x[q];
+            __syncthreads();
+        }
+        for (int t = tid; t < k; t += 256) out[(size_t)i * KP + colpos(t, NT)] = x[t];
+    }
 }
 
 // squared residuals of one timestamp row (trmf_session_objective): sum (y - w.h)^2, products in val_type, sum in double

@@ -471,7 +471,7 @@ struct TrmfSessionImpl {
         nbe = (int)std::min<size_t>(kMaxPartials, (NV + 255) / 256);
         rpb = std::max(1, 256 / k);
         nba = std::min(kMaxPartials, (T + rpb - 1) / rpb);
-        if (full) {      // apply_shared_mfma_kernel: a 16-row tile per wavefront and pass, <= 2 workgroups per CU resident, equal passes
+        if (full && !generic) {      // apply_shared_mfma_kernel: a 16-row tile per wavefront and pass, <= 2 workgroups per CU resident, equal passes
             const int blocks = ((T + kApplyTile - 1) / kApplyTile + 3) / 4, passes = (blocks + 511) / 512;
             nba = std::max(1, (blocks + passes - 1) / passes);
             const size_t need = apply_shared_lds_bytes(KP);
@@ -1069,6 +1069,18 @@ struct TrmfSessionImpl {
                                gemm_part.p, nchunk, M, KP, NT, k, out);
     }
     int y_times_factor(bool transposed, const real *X, real *out, uint32_t rb, uint32_t re) {
+        if (generic) {
+            if (!dense) {
+                if (re > rb)
+                    hipLaunchKernelGGL(spmm_generic_kernel, dim3(std::min<uint32_t>(4096, re - rb)), dim3(256), 0, stream, transposed ? Yc_ptr.p : Yr_ptr.p,
+                                       transposed ? Yc_idx.p : Yr_idx.p, transposed ? Yc_val.p : Yr_val.p, X, out, rb, re, k, KP, NT);
+            } else {
+                const int K = transposed ? T : n, M = transposed ? n : T;
+                hipLaunchKernelGGL(dense_tn_generic_kernel, dim3(std::min(4096, std::max(1, M))), dim3(256), 0, stream, transposed ? Yd_tn.p : Yd_nt.p, K, M, X, out, k, KP, NT);
+            }
+            TRMF_HIP_CHECK(hipGetLastError());
+            return 0;
+        }
         if (!dense) {
             const uint32_t *ptr = transposed ? Yc_ptr.p : Yr_ptr.p, *idx = transposed ? Yc_idx.p : Yr_idx.p;
             const real *val = transposed ? Yc_val.p : Yr_val.p;
@@ -1096,6 +1108,10 @@ struct TrmfSessionImpl {
         hipLaunchKernelGGL((small_gram_mfma_kernel<NT_>), dim3(nb), dim3(256), 0, stream, A, rows, k, sgram_part.p);
     }
     int small_gram(const real *A, int rows, real lambda, real *GS) {
+        if (generic) {
+            hipLaunchKernelGGL(small_gram_generic_kernel, dim3(k), dim3(256), 0, stream, A, rows, k, KP, NT, lambda, GS);
+            return 0;
+        }
         // one partial per wavefront (4 per workgroup), at least 64 rows each, kSmallGramBlocks slots in all
         const int nb = std::max(1, std::min(kSmallGramBlocks / 4, rows / 256));
         switch (NT) {
@@ -1112,7 +1128,12 @@ struct TrmfSessionImpl {
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
         if (y_times_factor(true, W.p, Bf.p, dense ? 0u : rb, dense ? (uint32_t)n : re)) return kFail;   // Y^T W
         small_gram(W.p, T, (real)lambdaI, GSf.p);                                                       // W^T W + lambda I
-        if (re > rb) {
+        if (re > rb && generic) {
+            hipLaunchKernelGGL(chol_generic_kernel, dim3(1), dim3(256), 0, stream, GSf.p, Uf.p, k);
+            const int nrows = (int)(re - rb);
+            hipLaunchKernelGGL(solve_rows_generic_kernel, dim3(std::min(2048, nrows)), dim3(256), (size_t)k * sizeof(real), stream, Uf.p, Bf.p + (size_t)rb * KP,
+                               H.p + (size_t)rb * KP, nrows, k, KP, NT);
+        } else if (re > rb) {
             const size_t ulds = (size_t)k * k * sizeof(real);          // <= 32 KB
             if (getenv("TRMF_CHOL_WORKGROUP")) hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
             else switch (NT) {
@@ -1476,7 +1497,8 @@ struct TrmfSessionImpl {
         // shared Gram, or the packed Grams of one row group, staged per workgroup
         const size_t ap_lds = full ? (size_t)k * k * sizeof(real) : gpacked ? (size_t)apply_stages(k) * 512 * sizeof(real) : 0;
         auto launch_apply = [&](int blocks, int row_b, int rows, int slot_b) {
-            if (k > kApplyThreadPerColumn) {       // very wide ranks: a workgroup per timestamp walks the columns
+            if (k > kApplyThreadPerColumn || (generic && full)) {   // very wide ranks (a workgroup per timestamp walks the columns); also the shared
+                                                                    // Gram of the full-observation path above rank 64 (read from L2, not staged in LDS)
                 hipLaunchKernelGGL(apply_wide_kernel, dim3(blocks), dim3(256), (size_t)k * sizeof(real), stream, xp, st, cg_it, operand, resid, arbase.p,
                                    Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), row_b, rows, slot_b);
                 return;
@@ -1495,7 +1517,7 @@ struct TrmfSessionImpl {
                 hipLaunchKernelGGL(apply_kernel<false>, dim3(blocks), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
                                    Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, row_b, rows, slot_b);
         };
-        if (full && !getenv("TRMF_NO_APPLY_SHARED")) {       // one Gram for every timestamp: the product runs on the matrix pipe (never sharded)
+        if (full && !generic && !getenv("TRMF_NO_APPLY_SHARED")) {       // one Gram for every timestamp: the product runs on the matrix pipe (never sharded)
 #define TRMF_LAUNCH_APPLY_SHARED(NTV)                                                                                           \
     hipLaunchKernelGGL((apply_shared_mfma_kernel<NTV>), dim3(nba), dim3(256), apply_shared_lds_bytes(KP), stream, xp, st, cg_it,  \
                        operand, resid, arbase.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), 0, T, 0)

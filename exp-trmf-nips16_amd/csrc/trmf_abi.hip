@@ -74,10 +74,8 @@ static bool check_device_limits(const PyMatrix *Y, const PyMatrix *W, uint32_t l
     // the reference asserts (aborts) on a dense Y with missing != 0 (rf_matrix.h:180); here: diagnostic
     if (missing && Y->type != TRMF_SPARSE) { fprintf(stderr, "[ERR MSG]: missing!=0 requires a sparse Y\n"); pass = false; }
     if (Y->type != TRMF_SPARSE && Y->type != TRMF_DENSE_ROWMAJOR && Y->type != TRMF_DENSE_COLMAJOR) { fprintf(stderr, "[ERR MSG]: unsupported Y matrix type %d\n", (int)Y->type); pass = false; }
-    // observed-entries path: register-tiled kernels up to rank 64, generic kernels (csrc/generic_kernels.hpp) up to 256; the
-    // full-observation path has the tiled kernels only
-    const int max_rank = missing ? kMaxRankGeneric : kMaxRank;
-    if (W->cols < 1 || W->cols > (uint64_t)max_rank) { fprintf(stderr, "[ERR MSG]: rank k=%ld outside the supported range 1..%d%s\n", (long)W->cols, max_rank, missing ? "" : " (missing == 0)"); pass = false; }
+    // register-tiled kernels up to rank 64, generic kernels (csrc/generic_kernels.hpp) up to 1024, on both training paths
+    if (W->cols < 1 || W->cols > (uint64_t)kMaxRankGeneric) { fprintf(stderr, "[ERR MSG]: rank k=%ld outside the supported range 1..%d\n", (long)W->cols, kMaxRankGeneric); pass = false; }
     if (lag_size > (uint32_t)kMaxLags) { fprintf(stderr, "[ERR MSG]: |lag_set|=%u exceeds the supported %d\n", lag_size, kMaxLags); pass = false; }
     if ((Y->type == TRMF_SPARSE && Y->nnz >= (1ull << 32)) || Y->rows >= (1ull << 31) || Y->cols >= (1ull << 31)) { fprintf(stderr, "[ERR MSG]: problem exceeds 32-bit device indices\n"); pass = false; }
     // gathered factor rows are addressed with 32-bit byte offsets (gram_ring): tables up to 4 GiB

@@ -89,7 +89,9 @@ typedef struct {
  * dimension error; the reference aborts on an assert, reads out of bounds or has no such limit):
  *   - missing != 0 with a dense Y                  (reference: assert, rf_matrix.h:180)
  *   - lag_set not ascending, max lag >= rows of Y  (reference: out-of-bounds reads)
- *   - rank k outside 1..64, more than 128 lags
+ *   - rank k outside 1..1024, more than 1024 lags (ranks up to 64 and lag sets whose |L| x |L| systems fit LDS run the
+ *     register-tiled kernels; beyond that generic kernels compute the same thing slowly -- csrc/generic_kernels.hpp --
+ *     where rounds 1-3 answered "[ERR MSG]")
  *   - a SPARSE Y with nnz >= 2^32; Y with >= 2^24 - 1 rows or columns, or a factor table
  *     (rows+1) x 16*ceil(k/16) elements above 4 GiB     (32-bit device offsets)
  *   - a lag reach / lag count whose LDS tiles exceed 160 KB per workgroup (session creation)

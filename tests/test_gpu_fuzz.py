@@ -164,13 +164,32 @@ def test_ranks_and_lag_sets_beyond_the_tiled_kernels(dtype, k, nlag, T, n):
     assert ('generic' in desc) == (k > 64)
 
 
+@pytest.mark.parametrize('dtype,k,kind', [(np.float64, 70, 'dense_c'), (np.float32, 96, 'dense_f'), (np.float64, 130, 'sparse'), (np.float32, 300, 'dense_c')])
+def test_full_observation_path_beyond_rank_64(dtype, k, kind):
+    """missing = 0 above rank 64: Y^T W / Y H, W^T W + lambda I, one Cholesky with n right-hand sides, the CG with one shared
+    Gram -- generic kernels (csrc/generic_kernels.hpp) in place of the MFMA ones.  Two iterations against the restatement."""
+    rng = np.random.RandomState(5 + k)
+    T, n, lags = 180, 50, np.array([1, 2, 5], dtype=np.uint32)
+    d = trmf.Model.syn_gen(T, n, 6, [1, 2], seed=k, dtype=np.float64)
+    Yd = (d['Y'] + 0.05 * rng.randn(T, n)).astype(dtype)
+    Y = {'dense_c': np.ascontiguousarray(Yd), 'dense_f': np.asfortranarray(Yd), 'sparse': smat.csr_matrix(np.where(rng.rand(T, n) < 0.5, Yd, 0))}[kind]
+    hyper = dict(lambdaI=0.5, lambdaAR=50.0, lambdaLag=0.5)
+    m0 = trmf.Model.initialize(Y, lags, k, seed=1, dtype=dtype)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    O.train_port(Y, m0.lag_set, W, H, Th, hyper, max_iter=2, missing=False, threads=4)
+    model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
+    trmf.train(Y, model, max_iter=2, missing=False, **hyper)
+    tol = TOL[np.dtype(dtype).name]
+    print('full path k=%d %s %s: relfro W %.1e H %.1e Th %.1e' % (k, kind, np.dtype(dtype).name, relfro(model.W, W), relfro(model.H, H), relfro(model.lag_val, Th)))
+    assert relfro(model.W, W) < tol['factor'] and relfro(model.H, H) < tol['factor'] and relfro(model.lag_val, Th) < 10 * tol['factor']
+
+
 def test_limits_that_remain_are_reported(capfd):
-    """What the drop-in still refuses, loudly and without touching the outputs: a rank above 1024 (observed-entries path) or
-    above 64 on the full-observation path, more than 1024 lags."""
+    """What the drop-in still refuses, loudly and without touching the outputs: a rank above 1024, more than 1024 lags."""
     rng = np.random.RandomState(0)
     T, n = 60, 30
     Yd = rng.randn(T, n)
-    for k, nlag, missing, what in ((1025, 2, True, 'rank k=1025'), (65, 2, False, 'rank k=65'), (4, 1025, True, '|lag_set|=1025')):
+    for k, nlag, missing, what in ((1025, 2, True, 'rank k=1025'), (1025, 2, False, 'rank k=1025'), (4, 1025, True, '|lag_set|=1025')):
         Y = smat.csr_matrix(Yd) if missing else Yd
         lags = np.arange(1, nlag + 1, dtype=np.uint32) if nlag < T else np.arange(nlag, dtype=np.uint32)
         m = trmf.Model.initialize(Y, lags, k, seed=0, dtype=np.float64)
