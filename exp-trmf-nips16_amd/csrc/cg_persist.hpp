@@ -16,15 +16,18 @@
 //     sees the tag sees the payload (the "LL" protocol of the collective libraries).  A tile's RECORD of a step (its three dot
 //     products) is eight such words and is its own arrival flag: every workgroup polls all records of the step and sums them
 //     in the single fixed order of hv_tile_kernel.  The tile's rows of H d (of g, of s) travel the same way, and the
-//     neighbours poll the midx rows they stage as halo.  (A first version stored the rows plainly -- write-through, waited
-//     for with vmcnt(0) before the record was published -- and read them once the owner's record had arrived: the rows were
-//     occasionally STALE.  A completed sc1 store is not yet visible device-wide; only the all-to-all of the records had
-//     hidden that.  Found by the bit-identity test, profiles/r04_persist_notes.txt.)  Buffers ping-pong by exchange parity:
-//     a workgroup can be at most one exchange ahead of any other.
+//     neighbours poll the midx rows they stage as halo.  (A first version stored the rows plainly (sc1), "waited" for them with a
+//     workgroup-scope release fence and read them once the owner's record had arrived: the rows were occasionally STALE -- that
+//     fence emits no s_waitcnt vmcnt(0) on gfx950, the stores were never drained before the record went out, and only the latency of
+//     the all-to-all had hidden it.  Found by the bit-identity test; profiles/r04_persist_notes.txt.  The price list of
+//     /opt/skills/guides/MI355X_MICROARCH.md has both forms -- "handoff-flag" with an explicit asm vmcnt(0) drain, and data-tagged
+//     granules at about half its latency; the granules need no drain and no ordering argument, so they are what is used.)  Buffers
+//     ping-pong by exchange parity: a workgroup can be at most one exchange ahead of any other.
 //
 // Same tiles, same per-thread element mapping, same arithmetic and summation order as hv_tile_kernel / cg_close_kernel /
 // accept_tile_kernel: the iterates are BIT-IDENTICAL to the launch-per-step path (tests/test_gpu_parity.py compares them).
-// Needs every workgroup co-resident (cooperative launch; the host checks the occupancy) and the GPU to itself: used with one
+// Needs every workgroup co-resident (the host checks the grid against the occupancy the runtime reports; a plain launch has the
+// same residency as a cooperative one and costs 15-19 us less host time, guide row "coop-launch") and the GPU to itself: used with one
 // rank per GPU; every poll is bounded (2 s), a timeout sets XState::p2p_error and ends the kernel.
 #pragma once
 
