@@ -236,7 +236,8 @@ def test_unsupported_inputs_fail_loudly(capfd):
     model = make_model(m0.W, m0.H, m0.lag_val, m0.lag_set)
     trmf.train(Yd, model, missing=True, max_iter=1)                 # dense Y needs missing=False
     assert 'requires a sparse Y' in capfd.readouterr().err and np.array_equal(model.W, W0)
-    big = make_model(np.zeros((30, 65), np.float32), np.zeros((20, 65), np.float32), np.zeros((2, 65), np.float32, order='F'), [1, 2])
+    # (ranks 65..1024 compute since round 4: tests/test_gpu_fuzz.py; the limit that remains is 1024)
+    big = make_model(np.zeros((30, 1025), np.float32), np.zeros((20, 1025), np.float32), np.zeros((2, 1025), np.float32, order='F'), [1, 2])
     trmf.train(smat.csr_matrix(Yd), big, missing=True, max_iter=1)
     assert 'outside the supported range' in capfd.readouterr().err
 
