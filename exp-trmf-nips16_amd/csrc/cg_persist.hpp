@@ -24,6 +24,12 @@
 //     granules at about half its latency; the granules need no drain and no ordering argument, so they are what is used.)  Buffers
 //     ping-pong by exchange parity: a workgroup can be at most one exchange ahead of any other.
 //
+// Several ranks (SHARD, one process per GPU; round 4): the same kernel, one launch per rank over the rank's block of tiles.  The
+// exchange is transport-agnostic: a record is stored into EVERY rank's copy of the record table, a row within midx of the
+// rank's block boundary also into the neighbouring rank's copy of the row table (system-scope stores into IPC-mapped, uncached
+// arenas), and every rank polls its own copies.  All ranks sum all records in the single-GPU order: bit-identical iterates for
+// any number of ranks, one kernel per solve per rank, no launch, no collective and no host involvement inside the solve.
+//
 // Same tiles, same per-thread element mapping, same arithmetic and summation order as hv_tile_kernel / cg_close_kernel /
 // accept_tile_kernel: the iterates are BIT-IDENTICAL to the launch-per-step path (tests/test_gpu_parity.py compares them).
 // Needs every workgroup co-resident (the host checks the grid against the occupancy the runtime reports; a plain launch has the
@@ -54,6 +60,12 @@ struct PersistArgs {
     int TI, maxcg;
     XState *log_x;                 // iteration record written by the accept phase (or null)
     double *log_n;
+    // several ranks (SHARD): this rank runs the tiles [sh.tile0, sh.tile0 + sh.ntiles) of sh.nbt; `ll` / `hll` are its OWN copies in
+    // its IPC-exported arena, peer_ll / peer_hll the other ranks' copies (null for the own rank)
+    TileShard sh;
+    unsigned long long *peer_ll[kMaxPeers];
+    unsigned long long *peer_hll[kMaxPeers];
+    long long timeout_ticks;       // bound of every poll (100 MHz ticks; kPersistTimeoutTicks unless TRMF_PERSIST_TIMEOUT_MS says otherwise)
     long long *prof;               // -DTRMF_PERSIST_PROF builds only: cycle stamps of the phases (tile 0 and the middle tile)
 };
 constexpr int kProfSlots = 8, kProfIters = 32;
@@ -96,8 +108,9 @@ template <typename R> __device__ __forceinline__ void ll_unpack(const pu4 &w, R 
     else dst[0] = (R)__longlong_as_double((long long)(((unsigned long long)w.z << 32) | (unsigned long long)w.x));
 }
 
-template <int KQ>
+template <int KQ, bool SHARD>
 __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *__restrict__ st, PersistArgs a) {
+    constexpr int kAuxLd = SHARD ? (kSc1 | 1) : kSc1;        // polls: device scope on one GPU, system scope when peers store into the arena
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
     __shared__ double keep[8];          // uniform scalars of the solve (f, |g|, ...): parked in LDS, not in registers, between their uses
@@ -109,7 +122,8 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     const int tid = threadIdx.x;
     const int k = p.k, T = p.T, Hh = p.midx, nlag = p.nlag, TI = a.TI;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh, nV = rowsV * KP, nTh = nlag * k;
-    const int tile = (int)blockIdx.x, nbt = (int)gridDim.x;
+    const int tile = (SHARD ? a.sh.tile0 : 0) + (int)blockIdx.x, nbt = SHARD ? a.sh.nbt : (int)gridDim.x;
+    const bool lead = blockIdx.x == 0 && threadIdx.x == 0;   // writes this rank's XState
     const int i0 = tile * TI, i1 = min(i0 + TI, T);
     const int own_n = (i1 - i0) * KP, own0 = Hh * KP;       // own rows: staged elements [own0, own0 + own_n)
     const int sz = (int)sizeof(real);
@@ -127,13 +141,13 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     double *recs = reinterpret_cast<double *>(hv_smem + (((size_t)(reinterpret_cast<unsigned char *>(lags + nlag) - hv_smem) + 15) / 16 * 16));   // [tiles][4]
     if (tid == 0) s_fail = 0;
 #if defined(TRMF_PERSIST_PROF)
-    const int prof_sel = tile == 0 ? 0 : tile == nbt / 2 ? 1 : -1;
+    const int prof_sel = blockIdx.x == 0 ? 0 : (int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1;
     auto stamp = [&](int iter, int slot) {
         if (a.prof && tid == 0 && prof_sel >= 0 && iter < kProfIters) a.prof[((size_t)prof_sel * kProfIters + iter) * kProfSlots + slot] = wall_clock64();
     };
     // every tile, CG iteration 5: [kProfAll + 2 * tile] = collect done, [+1] = record published
     const size_t kProfAll = (size_t)2 * kProfIters * kProfSlots;
-    auto stamp_all = [&](int iter, int which) { if (a.prof && tid == 0 && iter == 5) a.prof[kProfAll + 2 * tile + which] = wall_clock64(); };
+    auto stamp_all = [&](int iter, int which) { if (a.prof && tid == 0 && iter == 5) a.prof[kProfAll + 2 * blockIdx.x + which] = wall_clock64(); };
 #else
     auto stamp = [&](int, int) {};
     auto stamp_all = [&](int, int) {};
@@ -207,14 +221,22 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
 
     // ---- exchange: publish this tile's record of exchange x, collect everybody's ----
     auto publish = [&](int x, double v0, double v1, double v2, double v3) {       // thread 0, after the tile's sc1 stores have been waited for
-        unsigned long long *rec = a.ll + ((size_t)(x & 1) * nbt + tile) * kLLWords;
+        const size_t ri = ((size_t)(x & 1) * nbt + tile) * kLLWords;
         const unsigned long long tag = (unsigned long long)(a.epoch0 + (uint32_t)x) << 32;
         const double v[4] = {v0, v1, v2, v3};
+        for (int r = 0; r < (SHARD ? a.sh.world : 1); r++) {
+            unsigned long long *rec = ((SHARD && r != a.sh.rank) ? a.peer_ll[r] : a.ll) + ri;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned long long bits = (unsigned long long)__double_as_longlong(v[q]);
-            __hip_atomic_store(rec + 2 * q, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(rec + 2 * q + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = 0; q < 4; q++) {
+                const unsigned long long bits = (unsigned long long)__double_as_longlong(v[q]);
+                if constexpr (SHARD) {
+                    __hip_atomic_store(rec + 2 * q, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __hip_atomic_store(rec + 2 * q + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                } else {
+                    __hip_atomic_store(rec + 2 * q, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(rec + 2 * q + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         }
     };
     // Collect exchange x: the records of ALL tiles -> LDS, and (halo) the midx rows on either side of the tile -> dst_staged.
@@ -234,14 +256,14 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     auto timed_out = [&](long long &t_start) -> bool {
         const long long now = wall_clock64();
         if (t_start == 0) { t_start = now; return false; }
-        return now - t_start > kPersistTimeoutTicks || __hip_atomic_load(&st->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        return now - t_start > a.timeout_ticks || __hip_atomic_load(&st->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
     };
     auto collect = [&](int x, int NF, double (&sum)[4], bool halo, real *dst_staged) -> bool {
         const uint32_t tag = a.epoch0 + (uint32_t)x;
         const int base = (x & 1) * nbt, wave = tid >> 6, lane = tid & 63;
         // records: wave w owns the chunks w, w + 4, ... (16 records each; lane = (record of the chunk, 16-byte quarter))
         constexpr int NCW = kPersistMaxTiles / 16 / 4;          // chunks per wave at most (8): polled in groups of NC
-        constexpr int NC = 3;
+        constexpr int NC = (KQ * VEC * (int)sizeof(real) / 4 >= 160) ? 2 : 3;   // (the 160-register Gram slices leave room for two requests in flight only)
         const int q = lane & 3, r = lane >> 2;
         uint32_t cpend = 0;                                      // wave-uniform: bit j = chunk wave + 4 j still incomplete
 #pragma unroll
@@ -276,11 +298,11 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
 #pragma unroll
                     for (int j = 0; j < NC; j++)
                         if ((cpend >> (g0 + j)) & 1u)
-                            wc[j] = __builtin_amdgcn_raw_buffer_load_b128(ll_rsrc, (base + min(16 * (wave + 4 * (g0 + j)) + r, nbt - 1)) * 64 + q * 16, 0, kSc1);
+                            wc[j] = __builtin_amdgcn_raw_buffer_load_b128(ll_rsrc, (base + min(16 * (wave + 4 * (g0 + j)) + r, nbt - 1)) * 64 + q * 16, 0, kAuxLd);
                     if (g0 == 0) {
 #pragma unroll
                         for (int m = 0; m < NU; m++)
-                            if (need[m]) wh[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_, vbyte0 * 2 + es[m] * EB, 0, kSc1);
+                            if (need[m]) wh[m] = __builtin_amdgcn_raw_buffer_load_b128(rs_, vbyte0 * 2 + es[m] * EB, 0, kAuxLd);
                     }
 #pragma unroll
                     for (int j = 0; j < NC; j++) {
@@ -300,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
                     }
                 }
                 if (!pending && !cpend) break;
-                if ((++passes & 63) == 0 && timed_out(t_start)) { atomicExch(&s_fail, 1); cpend = 0; break; }
+                if ((++passes & 63) == 0 && timed_out(t_start)) { atomicExch(&s_fail, cpend ? 1 : 2); cpend = 0; break; }   // 1: records missing, 2: halo rows
                 __builtin_amdgcn_s_sleep(0);
             }
         }
@@ -315,7 +337,11 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         if (NF > 3) acc[3] = block_allsum(acc[3], smem);
         sum[0] = acc[0]; sum[1] = acc[1]; sum[2] = acc[2]; sum[3] = acc[3];
         if (s_fail) {                                        // read after the barriers of the block sums: uniform in the workgroup
-            if (tid == 0) __hip_atomic_store(&st->p2p_error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) {
+                if (!__hip_atomic_exchange(&st->p2p_error, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {   // the first workgroup to give up says where
+                    st->p2p_diag[0] = x; st->p2p_diag[1] = tile; st->p2p_diag[2] = s_fail; st->p2p_diag[3] = 0;
+                }
+            }
             return false;
         }
         return true;
@@ -326,8 +352,24 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         const uint32_t tag = a.epoch0 + (uint32_t)x;
         const __amdgpu_buffer_rsrc_t rs_ = buffer_rsrc(reinterpret_cast<const unsigned char *>(a.hll) + ((size_t)(x & 1) * hll_elems + (size_t)i0 * KP) * EB,
                                                        (size_t)own_n * EB);
+        constexpr int kAuxSt = SHARD ? (kSc1 | 1) : kSc1;
         for (int u = tid; u < own_n / PER; u += 256) {
-            __builtin_amdgcn_raw_buffer_store_b128(ll_pack<real>(src_own, u, tag), rs_, u * 16, 0, kSc1);
+            __builtin_amdgcn_raw_buffer_store_b128(ll_pack<real>(src_own, u, tag), rs_, u * 16, 0, kAuxSt);
+        }
+        if constexpr (SHARD) {
+            // rows within midx of this rank's block boundary are the neighbouring rank's halo: also into its copy
+            const size_t off = ((size_t)(x & 1) * hll_elems + (size_t)i0 * KP) * EB;
+            const bool lo = a.sh.rank > 0 && i0 < a.sh.row_b + Hh, hi = a.sh.rank + 1 < a.sh.world && i1 > a.sh.row_e - Hh;
+            if (lo || hi) {
+                const __amdgpu_buffer_rsrc_t rlo = buffer_rsrc(reinterpret_cast<const unsigned char *>(lo ? a.peer_hll[a.sh.rank - 1] : a.hll) + off, (size_t)own_n * EB);
+                const __amdgpu_buffer_rsrc_t rhi = buffer_rsrc(reinterpret_cast<const unsigned char *>(hi ? a.peer_hll[a.sh.rank + 1] : a.hll) + off, (size_t)own_n * EB);
+                for (int u = tid; u < own_n / PER; u += 256) {
+                    const int i = i0 + (u * PER) / KP;
+                    const pu4 w = ll_pack<real>(src_own, u, tag);
+                    if (lo && i < a.sh.row_b + Hh) __builtin_amdgcn_raw_buffer_store_b128(w, rlo, u * 16, 0, kAuxSt);
+                    if (hi && i >= a.sh.row_e - Hh) __builtin_amdgcn_raw_buffer_store_b128(w, rhi, u * 16, 0, kAuxSt);
+                }
+            }
         }
     };
 
@@ -529,7 +571,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             rho_d = fmax(rho_prev_d - 2.0 * ad * sum[1] + ad * ad * sum[2], 0.0);
             const real rho = (real)rho_d;
             stopped = it == a.maxcg || cg_stopped(rho, cgtol);
-            if (tile == 0 && tid == 0) st->rho_hist[it] = rho_d;
+            if (lead) st->rho_hist[it] = rho_d;
             if (stopped) { stop_it = it; if (tid == 0) keep[2] = rho_d; break; }
             cg_iter = it + 1;
             const real beta = rho / rho_prev;
@@ -566,7 +608,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         stamp(it + 1, 5);
         it++;
     }
-    if (tile == 0 && tid == 0 && stop_it == 0) st->rho_hist[0] = rho_prev_d;
+    if (lead && stop_it == 0) st->rho_hist[0] = rho_prev_d;
 
     // =========================== close the last completed iteration (cg_close_kernel) ===========================
     // s += alpha d, r' = r - alpha Hd (own rows; stop_it == 0: s = 0, r = -g), sums <g,s>, <s,r'>, <s,s>
@@ -614,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     if (accept)
         for (int e = tid; e < own_n; e += 256) { real *wp = a.W + (size_t)i0 * KP + e; *wp = *wp + sown[e]; }   // w_new = w + s (rf_tron.h:183-184)
     stamp(kProfIters - 1, 0);
-    if (tile == 0 && tid == 0) {
+    if (lead) {
         const double rho = (double)(real)rho_stop;
         st->f = f; st->fnew = fnew; st->gnorm = gnorm; st->cgtol = cgtol; st->gs = gsr; st->sr = srr;
         st->prered = prered; st->actred = actred; st->accepted = accept ? 1 : 0; st->cg_iter = cg_iter;

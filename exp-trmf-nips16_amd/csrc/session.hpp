@@ -139,6 +139,8 @@ struct TrmfSessionImpl {
         std::vector<void *> peer;             // opened arenas of the other ranks (own slot: nullptr)
         unsigned long long epoch[3] = {0, 0, 0};
         double *msg[3] = {nullptr, nullptr, nullptr};   // this rank's three messages inside the arena
+        size_t ext_off = 0, ext_bytes = 0;    // tail of the arena: the persistent kernel's record table + tagged vector rows (cg_persist.hpp, SHARD)
+        size_t ext_ll_bytes = 0;
         std::string note;                     // why the peer-to-peer transport is unavailable (empty: available or not tried)
     } p2p;
     bool p2p_use = false;                     // transport of the CURRENT X-solve (select_transport)
@@ -149,12 +151,12 @@ struct TrmfSessionImpl {
     // per-launch exchange through the communicator or peer to peer.  Forced by TRMF_CG, else measured once: every candidate
     // runs two X phases (the second timed on every rank), the slowest rank's time decides.  The peer-to-peer transport is
     // a candidate whenever its set-up (IPC arenas + a trial exchange with a short bound) succeeded on every rank.
-    enum { kXRep = 0, kXTsComm = 1, kXTsP2p = 2, kXForms = 3 };
+    enum { kXRep = 0, kXTsComm = 1, kXTsP2p = 2, kXTsPersist = 3, kXForms = 4 };
     int x_form = kXRep;                       // the decided form; -1 while the candidates are being measured
     std::vector<int> x_cands;
     int x_calls = 0, cg_pred = 4;
-    float x_ms[kXForms] = {0, 0, 0};          // X phase of the measured call of each candidate (this rank)
-    double x_ms_all[kXForms] = {0, 0, 0};     // ... the slowest rank's (after the decision)
+    float x_ms[kXForms] = {0, 0, 0, 0};       // X phase of the measured call of each candidate (this rank)
+    double x_ms_all[kXForms] = {0, 0, 0, 0};     // ... the slowest rank's (after the decision)
     hipEvent_t ts0 = nullptr, ts1 = nullptr;
     int ar_TI = 64, nbar = 1;                 // unfused path: timestamps per ar_tile_kernel workgroup, its partial-sum slots
     DevBuf<real> arbase;                      // lambdaI*v + lambdaAR*AR'(v) between ar_tile_kernel and apply_kernel
@@ -195,7 +197,7 @@ struct TrmfSessionImpl {
     // rank, every rank releases what it has and the session goes on with the communicator transport (p2p.note says why;
     // one line on stderr under verbose or TRMF_P2P_VERBOSE).  `required` (TRMF_CG=p2p: explicitly requested) turns
     // "unavailable" into an error instead.  Returns kFail only for that and for a failing communicator.
-    int setup_p2p(size_t msg_doubles, bool required) {
+    int setup_p2p(size_t msg_doubles, bool required, size_t ext_ll_bytes = 0, size_t ext_hll_bytes = 0) {
         const int W_ = comm->world, me = comm->rank;
         auto unavailable = [&](const std::string &why) -> int {          // taken by EVERY rank together
             release_p2p();
@@ -223,7 +225,10 @@ struct TrmfSessionImpl {
         };
         // ---- stage 1: arena + handle ----
         const size_t msg_bytes = (msg_doubles * sizeof(double) + 255) / 256 * 256, flag_bytes = (size_t)3 * W_ * kFlagStride * sizeof(unsigned long long);
-        p2p.bytes = 3 * msg_bytes + flag_bytes;
+        p2p.ext_off = (3 * msg_bytes + flag_bytes + 255) / 256 * 256;
+        p2p.ext_ll_bytes = (ext_ll_bytes + 255) / 256 * 256;
+        p2p.ext_bytes = p2p.ext_ll_bytes + ext_hll_bytes;
+        p2p.bytes = p2p.ext_off + p2p.ext_bytes;
         unsigned char mine[kSlot] = {0};
         bool ok = !p2p_forced_failure("alloc") && hipExtMallocWithFlags(&p2p.arena, p2p.bytes, hipDeviceMallocUncached) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); p2p.arena = nullptr; }
@@ -392,6 +397,7 @@ struct TrmfSessionImpl {
         if (full && (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || Uf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
                      sgram_part.alloc((size_t)kSmallGramBlocks * k * k)))
             return kFail;
+        if (comm->world > 1 && count_ranks_per_device()) return kFail;
         if (alloc_time_scratch()) return kFail;
 
         events.resize(kEventRing);
@@ -400,7 +406,7 @@ struct TrmfSessionImpl {
             for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
         for (hipEvent_t *ev : {&gx0, &gx1, &gx2, &fs0, &fs1, &fs2, &ts0, &ts1}) TRMF_HIP_CHECK(hipEventCreate(ev));
-        if (gramx_times.alloc((size_t)4 * comm->world)) return kFail;
+        if (gramx_times.alloc((size_t)8 * comm->world)) return kFail;
         if (comm->world == 1) { gramx_mode = kGramxShard; fs_mode = kShardOn; }     // nothing to decide
         if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
         if (const char *e = getenv("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
@@ -484,7 +490,7 @@ struct TrmfSessionImpl {
             }
             if (rc) return kFail;
         }
-        tile_TI = 0; nbt = 1; persist_state = 0;
+        tile_TI = 0; nbt = 1; persist_state = 0; persist_shard_state = 0; persist_failed = false; persist_note.clear();
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
             int TI = hv_tile_rows(k);
             if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
@@ -595,7 +601,9 @@ struct TrmfSessionImpl {
         // peer-to-peer arena: required under TRMF_CG=p2p, otherwise tried (and silently dropped where it does not work) so
         // that the measure-once rule can consider it; never with TRMF_CG=timeshard|replicate or TRMF_NO_P2P
         const char *e = getenv("TRMF_CG");
-        if (ts_possible && ((e && e[0] == 'p') || (!e && !getenv("TRMF_NO_P2P"))) && setup_p2p(doubles, e != nullptr)) return kFail;
+        const bool ptables = nbt <= kPersistMaxTiles;             // the persistent kernel's tables ride in the same arena
+        if (ts_possible && ((e && e[0] == 'p') || (!e && !getenv("TRMF_NO_P2P"))) &&
+            setup_p2p(doubles, e != nullptr, ptables ? (size_t)2 * nbt * kLLWords * 8 : 0, ptables ? (size_t)2 * T * KP * 2 * sizeof(real) : 0)) return kFail;
         return 0;
     }
     // candidates of the X-solve's form, called once the geometry (tiles, uts) and the peer-to-peer arena are settled
@@ -605,15 +613,29 @@ struct TrmfSessionImpl {
         const char *e = getenv("TRMF_CG");
         const bool fused_ts = tile_TI > 0 && ts_possible;
         if (!fused_ts && !uts) return;                                   // one rank, or nothing time-sharded: no choice
+        if (fused_ts && e && e[0] == 'p' && e[1] == 'e') {              // "persist": one persistent kernel per rank
+            if (!persist_usable_shard()) { x_form = kXTsP2p; persist_note = "TRMF_CG=persist: tiles not co-resident / tables missing, peer-to-peer launches instead"; return; }
+            x_form = kXTsPersist; return;
+        }
         if (e && e[0] == 'p') { x_form = kXTsP2p; return; }              // set-up succeeded, or create() has failed already
         if (e && e[0] == 't') { x_form = kXTsComm; return; }
         if (fused_ts && e && e[0] == 'r') { x_form = kXRep; return; }
         if (fused_ts) x_cands.push_back(kXRep);
         x_cands.push_back(kXTsComm);
         if (p2p.on) x_cands.push_back(kXTsP2p);
+        // the persistent kernel across ranks: measured in the set-up iterations only (a trial that times out -- workgroups of several
+        // ranks that share ONE device and do not fit together -- costs the iteration it ran in, which autotune() undoes)
+        const char *at = getenv("TRMF_AUTOTUNE");
+        if (fused_ts && p2p.on && !(at && atoi(at) == 0) && !getenv("TRMF_NO_PERSIST_SHARD") && persist_usable_shard()) {
+            if (max_ranks_per_device <= 2) x_cands.push_back(kXTsPersist);
+            else persist_note = std::to_string(max_ranks_per_device) + " ranks share one device: the persistent-kernel form is not tried";
+        }
         x_form = x_cands.size() == 1 ? x_cands[0] : -1;
     }
-    static const char *x_form_name(int f) { return f == kXRep ? "replicated" : f == kXTsComm ? "time-sharded (communicator)" : f == kXTsP2p ? "time-sharded (peer to peer)" : "measuring"; }
+    static const char *x_form_name(int f) {
+        return f == kXRep ? "replicated" : f == kXTsComm ? "time-sharded (communicator)" : f == kXTsP2p ? "time-sharded (peer to peer)"
+             : f == kXTsPersist ? "time-sharded (one persistent kernel per rank, peer to peer)" : "measuring";
+    }
 
     // ---- per-series affine transform of a resident dense Y (trmf_session_set_series_transform) -------------------------
     // rolling_validate(transform=True) -- the paper scripts' setting -- refits a NormalizedTransform on every growing
@@ -1276,8 +1298,8 @@ struct TrmfSessionImpl {
     DevBuf<long long> persist_prof;           // -DTRMF_PERSIST_PROF builds: phase stamps of the last solve (printed by sync())
     uint32_t persist_epoch = 1;
     int persist_state = 0;                    // 0: not examined yet, 1: usable, -1: not
-    template <int KQ> int persist_prepare(size_t lds) {
-        const void *fn = reinterpret_cast<const void *>(&cg_persist_kernel<KQ>);
+    template <int KQ, bool SHARD = false> int persist_prepare(size_t lds) {
+        const void *fn = reinterpret_cast<const void *>(&cg_persist_kernel<KQ, SHARD>);
         if (lds > kLdsMax) return 0;
         if (lds > kLdsDefault && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
         int per_cu = 0, dev = 0;
@@ -1288,10 +1310,10 @@ struct TrmfSessionImpl {
         // kernel's ~106 SGPRs -- the register-bound answer of 2..3 is always the smaller one; capped anyway)
         return std::min(per_cu, 4) * prop.multiProcessorCount;
     }
-    template <int KQ> int persist_launch(const PersistArgs &pa, size_t lds) {
+    template <int KQ, bool SHARD = false> int persist_launch(const PersistArgs &pa, size_t lds) {
         // a plain launch: the grid was checked against the occupancy in persist_prepare(); hipLaunchCooperativeKernel gives the same
         // residency for 15-19 us more host time per launch (MI355X guide, "coop-launch")
-        hipLaunchKernelGGL((cg_persist_kernel<KQ>), dim3(nbt), dim3(256), lds, stream, xp, xstate.p, pa);
+        hipLaunchKernelGGL((cg_persist_kernel<KQ, SHARD>), dim3(SHARD ? tsh_rank.ntiles : nbt), dim3(256), lds, stream, xp, xstate.p, pa);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }
@@ -1322,10 +1344,71 @@ struct TrmfSessionImpl {
         }
         return persist_state == 1;
     }
-    int xsolve_persist(int maxcg, XState *log_x, double *log_n) {
+    // How many ranks drive the device that hosts the most of them (1 on a real node: one process per GPU).  Persistent kernels of
+    // several processes on ONE device only make progress while all of them are scheduled at once.  Measured with processes standing
+    // in for GPUs (profiles/r04_persist_notes.txt): 2 processes fine; 4 fine while their other kernels are short, but time-sliced to
+    // ~7 s per solve when every rank also runs the full F-solve (a 30 s poll bound lets it finish: slow progress, no lost data); 8
+    // processes ~30 s per solve.  With more than two ranks on one device the measure-once rule therefore leaves that form out;
+    // every poll stays bounded (2 s), and a trial that times out only loses the candidate.
+    int max_ranks_per_device = 1;
+    int count_ranks_per_device() {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        TRMF_HIP_CHECK(hipGetDevice(&dev));
+        TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int W_ = comm->world;
+        long long mine[8] = {prop.pciDomainID, prop.pciBusID, prop.pciDeviceID, 0, 0, 0, 0, 0};
+        DevBuf<long long> ids;
+        if (ids.alloc((size_t)8 * W_)) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(ids.p + 8 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice, stream));
+        if (comm->allgather_slots(ids.p, sizeof mine, stream)) return kFail;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<long long> all((size_t)8 * W_);
+        TRMF_HIP_CHECK(hipMemcpy(all.data(), ids.p, all.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        max_ranks_per_device = 1;
+        for (int a = 0; a < W_; a++) {
+            int same = 0;
+            for (int b = 0; b < W_; b++) same += all[8 * a] == all[8 * b] && all[8 * a + 1] == all[8 * b + 1] && all[8 * a + 2] == all[8 * b + 2];
+            max_ranks_per_device = std::max(max_ranks_per_device, same);
+        }
+        return 0;
+    }
+    // several ranks: every rank's tiles in one persistent kernel, tables in the IPC arenas (cg_persist.hpp, SHARD)
+    int persist_shard_state = 0;
+    bool persist_failed = false;
+    std::string persist_note;
+    bool persist_usable_shard() {
+        if (persist_shard_state == 0) {
+            persist_shard_state = -1;
+            const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);
+            if (p2p.on && p2p.ext_bytes > 0 && tile_TI > 0 && ts_possible && nbt <= kPersistMaxTiles && maxcg <= kCgHistCap && !full) {
+                const size_t lds = persist_lds_bytes(tile_TI, midx, KP, nlag, k, nbt);
+                int slots = 0;
+#define TRMF_PERSIST_PREP_S(KQV) slots = persist_prepare<KQV, true>(lds)
+                TRMF_PERSIST_SWITCH(TRMF_PERSIST_PREP_S)
+#undef TRMF_PERSIST_PREP_S
+                if (slots >= tsh_rank.ntiles) persist_shard_state = 1;
+            }
+        }
+        return persist_shard_state == 1;
+    }
+    int xsolve_persist(int maxcg, XState *log_x, double *log_n, bool shard = false) {
         PersistArgs pa{};
         pa.W = W.p; pa.Bv = Bv.p; pa.G = Gmat(); pa.lag_set = lag_set.p; pa.theta = theta.p;
         pa.hll = ll_vec.p; pa.ll = ll_rec.p;
+        if (shard) {
+            pa.sh = tsh_rank;
+            unsigned char *own = (unsigned char *)p2p.arena + p2p.ext_off;
+            pa.ll = reinterpret_cast<unsigned long long *>(own);
+            pa.hll = reinterpret_cast<unsigned long long *>(own + p2p.ext_ll_bytes);
+            for (int r = 0; r < comm->world; r++) {
+                unsigned char *pr = r == comm->rank ? nullptr : (unsigned char *)p2p.peer[r] + p2p.ext_off;
+                pa.peer_ll[r] = reinterpret_cast<unsigned long long *>(pr);
+                pa.peer_hll[r] = pr ? reinterpret_cast<unsigned long long *>(pr + p2p.ext_ll_bytes) : nullptr;
+            }
+        }
+        pa.timeout_ticks = kPersistTimeoutTicks;
+        if (const char *e = getenv("TRMF_PERSIST_TIMEOUT_MS")) pa.timeout_ticks = std::max(1ll, atoll(e)) * 100000ll;
         pa.epoch0 = persist_epoch; pa.TI = tile_TI; pa.maxcg = maxcg; pa.log_x = log_x; pa.log_n = log_n;
         persist_epoch += (uint32_t)maxcg + 8;
 #if defined(TRMF_PERSIST_PROF)
@@ -1335,9 +1418,10 @@ struct TrmfSessionImpl {
         }
 #endif
         const size_t lds = persist_lds_bytes(tile_TI, midx, KP, nlag, k, nbt);
-#define TRMF_PERSIST_GO(KQV) if (persist_launch<KQV>(pa, lds)) return kFail
+#define TRMF_PERSIST_GO(KQV) if (shard ? persist_launch<KQV, true>(pa, lds) : persist_launch<KQV, false>(pa, lds)) return kFail
         TRMF_PERSIST_SWITCH(TRMF_PERSIST_GO)
 #undef TRMF_PERSIST_GO
+        if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return 0;
     }
 #undef TRMF_PERSIST_SWITCH
@@ -1349,18 +1433,18 @@ struct TrmfSessionImpl {
     // timing the replicated form while the Gram build was still in ITS measuring mode biased the comparison).
     int decide_x_form() {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        double mine[4] = {(double)x_ms[0], (double)x_ms[1], (double)x_ms[2], 0};
-        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 4 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
+        double mine[8] = {(double)x_ms[0], (double)x_ms[1], (double)x_ms[2], (double)x_ms[3], 0, 0, 0, 0};
+        TRMF_HIP_CHECK(hipMemcpy(gramx_times.p + 8 * comm->rank, mine, sizeof mine, hipMemcpyHostToDevice));
         std::vector<uint64_t> off(comm->world + 1);
         for (int r = 0; r <= comm->world; r++) off[r] = (uint64_t)r * sizeof mine;
         if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<double> all((size_t)4 * comm->world);
+        std::vector<double> all((size_t)8 * comm->world);
         TRMF_HIP_CHECK(hipMemcpy(all.data(), gramx_times.p, all.size() * sizeof(double), hipMemcpyDeviceToHost));
         int best = x_cands[0];
         for (int f : x_cands) {
             x_ms_all[f] = 0;
-            for (int r = 0; r < comm->world; r++) x_ms_all[f] = std::max(x_ms_all[f], all[4 * r + f]);
+            for (int r = 0; r < comm->world; r++) x_ms_all[f] = std::max(x_ms_all[f], all[8 * r + f]);
             if (x_ms_all[f] < x_ms_all[best]) best = f;
         }
         x_form = best;
@@ -1585,6 +1669,7 @@ struct TrmfSessionImpl {
         if (!choice) form = kXRep;
         const bool shard = fused && form != kXRep;
         const int timed_form = form;
+        const bool measuring = choice && x_form < 0;
         select_transport(form == kXTsP2p);
         if (timed) TRMF_HIP_CHECK(hipEventRecord(ts0, stream));
         if (full) {
@@ -1602,7 +1687,28 @@ struct TrmfSessionImpl {
         };
         if (fused) {
             if (!shard && persist_usable(maxcg)) { if (xsolve_persist(maxcg, log_x, log_n)) return kFail; }
-            else if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
+            else if (form == kXTsPersist) {
+                if (xsolve_persist(maxcg, log_x, log_n, true)) return kFail;
+                if (measuring) {
+                    // a trial that timed out (ranks sharing one device whose workgroups do not fit together) must not fail the session:
+                    // the candidate loses, the error flag is cleared, the set-up iterations' effect on the factors is undone anyway
+                    TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+                    int err = 0;
+                    TRMF_HIP_CHECK(hipMemcpy(&err, &xstate.p->p2p_error, sizeof(int), hipMemcpyDeviceToHost));
+                    if (err) {
+                        if (getenv("TRMF_P2P_VERBOSE")) {
+                            XState hx;
+                            TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));
+                            fprintf(stderr, "[persist trial] rank %d: error %d, exchange %lld, tile %lld, missing %lld (1 records, 2 halo rows) %lld (tiles %d..%d of %d)\n",
+                                    comm->rank, err, hx.p2p_diag[0], hx.p2p_diag[1], hx.p2p_diag[2], hx.p2p_diag[3], tsh_rank.tile0, tsh_rank.tile0 + tsh_rank.ntiles, nbt);
+                        }
+                        TRMF_HIP_CHECK(hipMemset(&xstate.p->p2p_error, 0, sizeof(int)));
+                        x_ms[kXTsPersist] = 1e9f; persist_failed = true;
+                        persist_note = "the persistent kernel's trial timed out";
+                    }
+                }
+            } else if (xsolve_fused(shard, maxcg, log_x, log_n)) return kFail;
+            if (timed && form == kXTsPersist && persist_failed) { timed = false; TRMF_HIP_CHECK(hipEventRecord(ts1, stream)); }
             return end_timed();
         }
         real *dbuf[2] = {d0.p, d1.p}, *rbuf[2] = {r.p, r1.p}, *hbuf[2] = {Hd.p, Hd1.p};
@@ -1764,7 +1870,7 @@ struct TrmfSessionImpl {
                  !rep_gram ? "own timestamps only (never gathered)" : gramx_mode == kGramxReplicate ? "replicated" : gramx_mode == kGramxShard ? "sharded + all-gather of G" : "sharded (undecided)",
                  x.c_str(), meas.empty() ? "" : " [slowest rank's X phase: ", meas.c_str(), meas.empty() ? "" : "]",
                  p2p.on ? "available" : "unavailable", p2p.note.empty() ? "" : ": ", p2p.note.c_str(), tuned_iters);
-        return buf;
+        return persist_note.empty() ? std::string(buf) : std::string(buf) + " (" + persist_note + ")";
     }
 
     // ---- the ALS loop (trmf.cpp:647-693) --------------------------------------------------------------------
@@ -1848,7 +1954,7 @@ struct TrmfSessionImpl {
             }
         }
 #endif
-        if (persist_state == 1) {   // a bounded poll of the persistent CG kernel ran out (never observed; the GPU must not hang)
+        if (persist_state == 1 || (persist_shard_state == 1 && x_form == kXTsPersist)) {   // a bounded poll of the persistent CG kernel ran out (never observed; the GPU must not hang)
             XState hx;
             TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));
             if (hx.p2p_error) { set_error("persistent CG kernel: an exchange between workgroups timed out (is another process using the GPU? TRMF_PERSIST=0 selects the launch-per-step path)"); return kFail; }

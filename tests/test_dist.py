@@ -88,7 +88,7 @@ def _single_process(p, m0, dtype, iters):
 @pytest.mark.parametrize('world,shape,mode', [(2, 'small', 'timeshard'), (2, 'odd', 'timeshard'), (2, 'c4', 'timeshard'),
                                               (4, 'c4', 'timeshard'), (8, 'c4', 'timeshard'), (3, 'c4', 'measure'),
                                               (4, 'c4', 'replicate'), (3, 'c4', 'overlap'), (2, 'odd', 'overlap'), (2, 'small', 'p2p'), (2, 'c4', 'p2p'), (4, 'c4', 'p2p'),
-                                              (8, 'c4', 'p2p')])
+                                              (8, 'c4', 'p2p'), (2, 'small', 'persist'), (3, 'odd', 'persist'), (2, 'c4', 'persist'), (4, 'c4', 'persist')])
 def test_time_sharded_cg_matches_single_process(world, shape, mode):
     """The CG sharded over TIME: every rank runs the tiles of its own block of timestamps, the tile
     records (three scalars per CG step) and midx halo rows per neighbour are exchanged after every launch.  Same
@@ -98,6 +98,10 @@ def test_time_sharded_cg_matches_single_process(world, shape, mode):
     'p2p': the peer-to-peer form of the exchange -- every rank's kernels write their tile records and edge rows straight
     into the other ranks' IPC-mapped message buffers and synchronise through flag words (bounded waits); here the "peers"
     are processes sharing the one GPU, the code path (IPC handles, remote stores, system-scope flags) is the multi-GPU one.
+    'persist': ONE persistent kernel per rank and solve (csrc/cg_persist.hpp, SHARD): tagged records into every rank's arena, tagged
+    edge rows into the neighbours', no launch and no sync kernel inside the solve.  (Up to 4 ranks here: persistent kernels of EIGHT
+    processes on one device are time-sliced against each other -- bit-identical too when run, but ~30 s per solve; with more than 4
+    ranks on one device the measure-once rule leaves the form out, and on a real node every rank has its own GPU.)
     'overlap': the all-gather of H in 2 / 4 chunks (a byte range per rank each) behind the next chunk of the F-solve, forced on at these sizes."""
     import dist_worker
     iters = 5 if mode == 'measure' else 3
@@ -113,6 +117,8 @@ def test_time_sharded_cg_matches_single_process(world, shape, mode):
             W, H, Th, cg, second_session_same = out[r][name][:5]
             assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val), (r, name)
             assert cg == cg1 and second_session_same
+            if mode == 'persist':
+                assert 'one persistent kernel per rank' in out[r][name][6], out[r][name][6]
 
 
 @pytest.mark.gpu
@@ -217,7 +223,7 @@ def test_config4_full_size_sharded_paths_on_one_gpu(world):
     iters = 2
     ref_dig, ref_cg = _c3_single_process_digests(iters)
     report = {}
-    for mode in ('replicate', 'timeshard', 'p2p', 'auto'):
+    for mode in ('replicate', 'timeshard', 'p2p', 'auto') + (('persist',) if world <= 4 else ()):
         # 'auto': NO switch set -- the path bench.py --gpus N takes: every measure-once decision (F rows, X-side Gram rows, the form
         # of the CG with the peer-to-peer transport as a candidate) taken in set-up iterations on the full problem
         env = {} if mode == 'auto' else {'TRMF_CG': mode, 'TRMF_FSHARD': 'shard', 'TRMF_GRAMX': 'shard'}
