@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ALS iterations/sec of the MI355X TRMF solver on BASELINE.json's headline workload.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--no-cpu-baseline] [--cg replicate|timeshard|p2p]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--no-cpu-baseline] [--cg replicate|timeshard|p2p|persist]
 
 A "step" is one ALS iteration (F-solve, X-solve, Theta-solve every 2nd iteration; trmf.cpp:647-693)
 over the synthetic config-3 problem (100k x 10k, 1% dense, k=40, |L|=16, fp32),
@@ -179,7 +179,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c3')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'shard'],
+    ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'persist', 'shard'],
                     help='multi-GPU CG form (sets TRMF_CG; default: the library measures replicated vs time-sharded)')
     ap.add_argument('--cpu-iters', type=int, default=10)
     ap.add_argument('--cpu-threads', type=int, default=0)
