@@ -1333,7 +1333,9 @@ struct TrmfSessionImpl {
             persist_state = -1;
             const char *e = getenv("TRMF_PERSIST");
             const size_t lds = persist_lds_bytes(tile_TI, midx, KP, nlag, k, nbt);
-            if (comm->world == 1 && tile_TI > 0 && nbt <= kPersistMaxTiles && maxcg <= kCgHistCap && !(e && atoi(e) == 0)) {
+            // one rank, or several ranks each with a device of its own running the REPLICATED CG (every rank all tiles, no interaction
+            // between the ranks' kernels); never where ranks share a device (their workgroups would have to be co-resident)
+            if ((comm->world == 1 || max_ranks_per_device == 1) && tile_TI > 0 && nbt <= kPersistMaxTiles && maxcg <= kCgHistCap && !(e && atoi(e) == 0)) {
                 int slots = 0;
 #define TRMF_PERSIST_PREP(KQV) slots = persist_prepare<KQV>(lds)
                 TRMF_PERSIST_SWITCH(TRMF_PERSIST_PREP)
@@ -1853,7 +1855,7 @@ struct TrmfSessionImpl {
         const bool fused = tile_TI > 0;
         std::string x;
         if (full) x = "full-observation path (shared Gram)";
-        else if (fused && ts_possible) x = std::string("fused CG ") + x_form_name(x_form);
+        else if (fused && ts_possible) x = std::string("fused CG ") + x_form_name(x_form) + (x_form == kXRep && persist_state == 1 ? " (one persistent kernel per solve on every rank)" : "");
         else if (fused) x = "fused CG replicated (too few tiles to shard over time)";
         else if (uts) x = std::string("unfused CG ") + x_form_name(x_form);
         else x = cg_shard ? "unfused CG, cached-Gram product sharded (H d rows gathered per step)" : "unfused CG replicated";
