@@ -627,7 +627,7 @@ struct TrmfSessionImpl {
         // ranks that share ONE device and do not fit together -- costs the iteration it ran in, which autotune() undoes)
         const char *at = getenv("TRMF_AUTOTUNE");
         if (fused_ts && p2p.on && !(at && atoi(at) == 0) && !getenv("TRMF_NO_PERSIST_SHARD") && persist_usable_shard()) {
-            if (max_ranks_per_device <= 2) x_cands.push_back(kXTsPersist);
+            if (max_ranks_per_device == 1) x_cands.push_back(kXTsPersist);
             else persist_note = std::to_string(max_ranks_per_device) + " ranks share one device: the persistent-kernel form is not tried";
         }
         x_form = x_cands.size() == 1 ? x_cands[0] : -1;
@@ -1350,8 +1350,9 @@ struct TrmfSessionImpl {
     // several processes on ONE device only make progress while all of them are scheduled at once.  Measured with processes standing
     // in for GPUs (profiles/r04_persist_notes.txt): 2 processes fine; 4 fine while their other kernels are short, but time-sliced to
     // ~7 s per solve when every rank also runs the full F-solve (a 30 s poll bound lets it finish: slow progress, no lost data); 8
-    // processes ~30 s per solve.  With more than two ranks on one device the measure-once rule therefore leaves that form out;
-    // every poll stays bounded (2 s), and a trial that times out only loses the candidate.
+    // processes ~30 s per solve; even 2 processes occasionally miss the 2 s bound (it won the measurement and then timed out in a later
+    // solve of the full-size test).  Where ranks SHARE a device the measure-once rule therefore leaves that form out (TRMF_CG=persist
+    // still forces it); with a device per rank every poll stays bounded (2 s) and a trial that times out only loses the candidate.
     int max_ranks_per_device = 1;
     int count_ranks_per_device() {
         int dev = 0;
