@@ -310,6 +310,15 @@ def main():
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
                          'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows'},
+            # the same launch priced in arithmetic (one rank only): upper triangle of the k x k Gram + rhs per observed entry,
+            # k^3/3 + 2 k^2 per system; fp64's MFMA pipe issues one v_mfma_f64_16x16x4 per ~100 cycles per SIMD on this chip
+            # (profiles/r03_f64_pipe_ubench.txt) -- config 5's F-solve is bound by THAT, not by HBM
+            'roofline_compute': None if world != 1 or not missing or ms_fk <= 0 else (lambda fl, pk, pm: {
+                'kernel': 'the F-solve kernel of `roofline`', 'bound': 'mfma', 'achieved': fl / (ms_fk * 1e-3) / 1e12, 'peak': pk, 'unit': 'TFLOP/s',
+                'frac': fl / (ms_fk * 1e-3) / 1e12 / pk, 'peak_issue_rate_measured': pm, 'frac_of_measured_issue_rate': fl / (ms_fk * 1e-3) / 1e12 / pm,
+                'algorithmic_flops_per_launch': fl, 'flop_model': 'nnz*(k*(k+1) + 2*k) + rows*(k^3/3 + 2*k^2); padded MFMA tiles are not counted'})(
+                    float(nnz) * (cfg['k'] * (cfg['k'] + 1) + 2 * cfg['k']) + float(cfg['n']) * (cfg['k'] ** 3 / 3.0 + 2.0 * cfg['k'] ** 2),
+                    157.3 if dtype == np.float32 else 78.6, 155.0 if dtype == np.float32 else 50.3),
             'phases_ms': {'F': float(np.mean([x['ms_F'] for x in st])), 'X': float(np.mean([x['ms_X'] for x in st])),
                           'Theta': float(np.mean([x['ms_LV'] for x in st])),
                           'cg_iter': [int(x['cg_iter']) for x in st]},

@@ -207,23 +207,35 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     uint32_t jraw; real yraw; bool vraw;                 // entries of iteration n+2 (as loaded)
     uint32_t jsel; real ysel;                            // entries of iteration n+1 (masked)
 
+    // Entries through buffer descriptors rebuilt per iteration ON THE SCALAR UNIT: base = the iteration's first entry, range = what
+    // is left of the row, the lane's offset a loop constant -- no vector instruction forms an address, a lane past the row's end is
+    // out of range and reads 0 (so y needs no mask).  (Rounds 1-3: add, compare, clamp, a 64-bit shift and two 64-bit adds per
+    // iteration on the vector ALUs, which the fp32 MFMAs share.)
+    const uint32_t lane_e = (c & 3u) * estride + g;      // the lane's entry of an iteration
     auto load_entries = [&](const GramDesc &d) {
-        const uint32_t p = d.e0 + (c & 3u) * estride + g;
-        vraw = p < d.end;
-        const uint32_t pc = vraw ? p : 0u;               // clamped: never reads out of bounds
-        jraw = idx[pc];
-        yraw = val[pc];
+        // wave-uniform; readfirstlane pins it (and with it the descriptors) to the scalar unit: written as a select the compiler
+        // forms a saturating VECTOR subtract and then walks the "divergent" descriptor in a waterfall loop
+        const uint32_t e0u = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.e0), endu = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.end);
+        uint32_t left;                                   // max(end, e0) - e0 on the scalar unit (see above)
+        asm("s_max_u32 %0, %1, %2\n\ts_sub_u32 %0, %0, %2" : "=&s"(left) : "s"(endu), "s"(e0u) : "scc");
+        vraw = lane_e < left;
+        const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t *>(idx + e0u), 0, (int)(left * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t vr = __builtin_amdgcn_make_buffer_rsrc(const_cast<real *>(val + e0u), 0, (int)(left * (uint32_t)sizeof(real)), 0x00020000);
+        jraw = __builtin_amdgcn_raw_buffer_load_b32(ir, lane_e * 4u, 0, 0);
+        real yv[1];
+        load_factor_slice(yv, vr, lane_e * (uint32_t)sizeof(real));
+        yraw = yv[0];
     };
     auto promote_entries = [&]() {                       // consumes loads issued one iteration ago
-        jsel = vraw ? jraw : zero_row;
-        ysel = vraw ? yraw : real(0);
+        // the factor row's BYTE offset (rows < 2^24, checked at session creation): multiplied once per iteration here, so that a
+        // group's address is one add whose first operand is the DPP quad broadcast (v_add_u32_dpp) instead of a move + multiply-add
+        jsel = __umul24(vraw ? jraw : zero_row, (uint32_t)(KP * sizeof(real)));
+        ysel = yraw;                                     // 0 past the row's end (out of the descriptor's range)
     };
     auto load_slices = [&](auto U, real (&x)[D][NT], real (&yx)[D]) {   // slot u <- factor row of group u
         constexpr int u = decltype(U)::value;
-        const uint32_t j = quad_bcast<u>(jsel);
         if constexpr (!RHS_PAD) yx[u] = quad_bcast<u>(ysel);
-        // row * row bytes + lane bytes as ONE full-rate v_mad_u32_u24 (rows < 2^24, checked at session creation)
-        load_factor_slice(x[u], x_rsrc, __umul24(j, (uint32_t)(KP * sizeof(real))) + lane_bytes);
+        load_factor_slice(x[u], x_rsrc, quad_bcast<u>(jsel) + lane_bytes);
     };
 
     GramDesc d1 = d0; next(d1);
@@ -231,8 +243,12 @@ __device__ __forceinline__ void gram_ring(GramState<NT> &st, const uint32_t *__r
     real x[D][NT], yx[D];
     load_entries(d0);
     promote_entries();
-    static_for<D>([&](auto U) { load_slices(U, x, yx); });
+    // entries of iteration 1 BEFORE the slices of iteration 0, the order of the loop body: the loop's first wait (for the
+    // entries loaded one iteration ago) is then "all but the four slice loads behind them" on both paths into the loop
+    // header.  With the entries requested last here (rounds 1-3) the wait merged over both paths was vmcnt(0): every
+    // iteration drained the four gathers it had just issued, and a wavefront's ring only overlapped with OTHER wavefronts.
     load_entries(d1);
+    static_for<D>([&](auto U) { load_slices(U, x, yx); });
     // Slot u is consumed (its MFMAs and rhs FMAs issued) and then immediately re-requested for the next
     // iteration, in place: every load still has a full iteration of MFMA time (24 x 32 cycles) to land, and
     // there is no second operand set to copy into (12 + 4 register moves per iteration that the shared
