@@ -13,9 +13,8 @@
 //   fsolve_kernel   one wavefront per item row: Gram in MFMA accumulators -> LDS -> one factor
 //                   column per lane in registers -> right-looking Cholesky with v_readlane
 //                   broadcasts -> forward/backward substitution -> row of F.  (trmf.cpp:369-397)
-//   gram_x_kernel   one 4-wave workgroup per timestamp row: Gram + rhs + loss of the X-side
-//                   sub-problem, cached in HBM for the CG (replaces the per-Hv re-streaming of
-//                   trmf.cpp:269-288).
+//   gram_x_kernel   one wavefront per timestamp row: Gram + rhs of the X-side sub-problem, cached in
+//                   HBM for the CG (replaces the per-Hv re-streaming of trmf.cpp:269-288).
 //   loss_kernel     sum of squared residuals per timestamp row (trmf.cpp:231-245, loss part).
 #pragma once
 
@@ -169,11 +168,14 @@ template <int NT> __host__ __device__ constexpr bool rhs_pad_ok(int k) { return 
 // e0 + (c&3)*estride + g; group u then takes its entry from quad lane u with a DPP quad_perm
 // broadcast) and FOUR vector loads of the gathered factor rows (column-interleaved layout: the NT
 // slices of a lane are contiguous).
-// The gathered factor rows are fetched through a buffer descriptor: address = descriptor base + ONE
-// 32-bit lane offset (row * row bytes + the lane's column bytes, two full-rate integer instructions),
-// instead of a 64-bit multiply-add per row (quarter rate, and the fp32 MFMA shares the vector ALUs
-// with every other VALU instruction -- scripts/ubench/mfma_valu.hip -- so each VALU cycle in this
-// loop is a cycle the Gram does not get).  Factor tables are therefore limited to 4 GiB.
+// The fp32 MFMA shares the vector ALUs with every other VALU instruction (scripts/ubench/mfma_valu.hip): each
+// VALU cycle in this loop is a cycle the Gram does not get, so addresses are formed off the vector ALUs where
+// they can be.  Entries: buffer descriptors rebuilt per iteration on the scalar unit (load_entries below).
+// Gathered factor rows: one buffer descriptor over the table, address = descriptor base + ONE 32-bit lane
+// offset = the row's byte offset (one multiply per iteration, promote_entries) broadcast within the quad and
+// added to the lane's column bytes in a single v_add_u32_dpp per group (rounds 1-3: a DPP move + a
+// multiply-add per group; before that a 64-bit multiply-add per row).  Factor tables are therefore limited to 4 GiB.
+// 15 vector instructions per iteration beside the 24 MFMAs at three column tiles (27 until round 4).
 // One load PER ELEMENT of the lane's slice (same descriptor, same lane offset, immediate offsets): a single
 // multi-dword load would force its destination into a register tuple, and the allocator then copies the
 // tuple's elements into the MFMA operand registers right after the load -- i.e. waits for it at once.
