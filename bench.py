@@ -12,7 +12,8 @@ all-gathers over xGMI), so total work is fixed: "scaling": 
 
 Rank 0 prints ONE JSON line.  `roofline` describes the F-solve kernel (HBM-bound under the
 gather-inclusive algorithmic byte model B_F of SURVEY.md 8(d) / BASELINE.md section 3), timed with HIP
-events recorded on the solver's own stream around that kernel.  `cpu_baseline` times the reference's
+events recorded on the solver's own stream around that kernel; `roofline_compute` prices the same launch in useful
+arithmetic against the dtype's matrix peak (config 5's fp64 F-solve is bound by that, not by HBM).  `cpu_baseline` times the reference's
 CPU path (oracle/_ref when present, else the C restatement) on this box's host cores with the protocol of
 BASELINE.md section 3 (min(physical, 64) and 8 threads, 2 warm-up + 10 timed iterations from the state the
 GPU's timed window started from, F / X / Theta split); it is a reported baseline, not the thing measured.
