@@ -148,13 +148,14 @@ def cpu_baseline(config, iters, state_file, gpu_file=''):
     import subprocess
     have_ref = os.path.exists(os.path.join(ROOT, 'oracle', '_ref', 'trmf_float32.so'))
     cores = physical_cores()
+    results = {}
     for kind in (['reference'] if have_ref else []) + ['port']:
         runs = []
         for threads in sorted({min(cores, 64), min(cores, 8)}, reverse=True):
             try:
                 res = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-baseline-worker', kind,
                                       '--config', config, '--cpu-iters', str(iters), '--cpu-threads', str(threads),
-                                      '--cpu-state', state_file or '', '--cpu-gpu-result', gpu_file or ''],
+                                      '--cpu-state', state_file or '', '--cpu-gpu-result', (gpu_file or '') if kind == ('reference' if have_ref else 'port') else ''],
                                      capture_output=True, text=True, timeout=1200)
                 line = [l for l in res.stdout.splitlines() if l.startswith('{')][-1]
                 r = json.loads(line)
@@ -165,12 +166,73 @@ def cpu_baseline(config, iters, state_file, gpu_file=''):
                 sys.stderr.write('cpu_baseline kind={} threads={} failed: {}\n'.format(kind, threads, exc))
         if runs:
             best = max(runs, key=lambda r: r['iter_per_s'])
-            return {'value': best['iter_per_s'], 'unit': 'iter/s', 'cores': best['threads'], 'kind': kind,
-                    'host_physical_cores': cores, 'cpu_model': cpu_model_name(), 'runs': runs,
-                    'sample': '{} timed ALS iterations of the same {} workload after 2 warm-up iterations, warm-started from the '
-                              'factors the GPU\'s timed window started from; per-phase seconds from single-phase calls '
-                              '(period_* > max_iter)'.format(iters, config)}
-    return None
+            results[kind] = {'value': best['iter_per_s'], 'unit': 'iter/s', 'cores': best['threads'], 'kind': kind, 'runs': runs}
+    if not results:
+        return None
+    # the headline baseline is the real reference build when it travelled with the tree (oracle/_ref), else the restatement; the
+    # other one is listed beside it (BASELINE.md section 3 asks for the build's own OpenMP restatement on all cores and on 8)
+    head = dict(results.get('reference') or results['port'])
+    head.update({'host_physical_cores': cores, 'cpu_model': cpu_model_name(),
+                 'sample': '{} timed ALS iterations of the same {} workload after 2 warm-up iterations, warm-started from the '
+                           'factors the GPU\'s timed window started from; per-phase seconds from single-phase calls '
+                           '(period_* > max_iter)'.format(iters, config)})
+    if 'reference' in results and 'port' in results:
+        head['restatement'] = results['port']
+    return head
+
+
+def x_byte_models(cfg, nnz, itemsize):
+    """Algorithmic bytes of the X phase (SURVEY.md 8(d) "X-side figures"): the Gram build B_G = nnz*(4+s+k*s) + (T+1)*8 +
+    T*(k^2+k)*s, and one CG pass over the cached Grams B_cg = T*k^2*s + 6*T*k*s."""
+    T, k, s = cfg['T'], cfg['k'], itemsize
+    return float(nnz) * (4 + s + k * s) + (T + 1) * 8.0 + float(T) * (k * k + k) * s, float(T) * k * k * s + 6.0 * T * k * s
+
+
+def roofline_x(cfg, nnz, dtype, missing, world, ms_xg, ms_x, cg_steps, described):
+    """The X phase priced like the F-solve: the Gram build under B_G, the CG solve as (steps, us per pass) against B_cg --
+    both from HIP events on the solver stream (TrmfIterStats.ms_X_gram / ms_X).  One rank, observed-entries path only."""
+    if world != 1 or not missing or ms_xg <= 0 or ms_x <= ms_xg:
+        return None
+    b_g, b_cg = x_byte_models(cfg, nnz, dtype.itemsize)
+    ms_cg = ms_x - ms_xg
+    passes = cg_steps + 2.0            # gradient + one product per CG step + H s
+    us_pass = 1e3 * ms_cg / passes
+    return {'gram': {'kernel': 'gram_x_kernel', 'bound': 'hbm', 'algorithmic_bytes_per_launch': b_g, 'avg_ms': ms_xg,
+                     'achieved': b_g / (ms_xg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': b_g / (ms_xg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     'byte_model': 'nnz*(4+s+k*s) + (T+1)*8 + T*(k^2+k)*s'},
+            'cg': {'form': described, 'avg_ms_per_solve': ms_cg, 'cg_steps_per_solve': cg_steps, 'operator_passes_per_solve': passes,
+                   'us_per_pass': us_pass, 'algorithmic_bytes_per_pass': b_cg, 'achieved': b_cg / (us_pass * 1e-6) / 1e9, 'peak': HBM_PEAK_GBPS,
+                   'unit': 'GB/s', 'frac': b_cg / (us_pass * 1e-6) / 1e9 / HBM_PEAK_GBPS,
+                   'byte_model': 'T*k^2*s + 6*T*k*s per pass over the cached Grams (the persistent kernel keeps its Gram slice in registers: '
+                                 'its HBM traffic per pass is the exchanged rows only, a pass is a latency chain -- DESIGN.md 4.4)'}}
+
+
+def measure_one_shot(prob, cfg, hyper, missing, dtype, iters, calls=4):
+    """The reference's own entry point as a caller of the reference API meets it: c_trmf_train(max_iter=iters) on host arrays --
+    upload, train, download -- wall clock around the C call, with the library's own split of it (trmf_last_train_profile).  The
+    first call of the process pays one-time costs (pinned ring, first slab of the pool); `steady` is the fastest later call
+    (what the second and later calls of a grid_search see)."""
+    import numpy as np
+    import trmf.trmf as front
+    from trmf import session, synth
+    from trmf.rf_util import PyMatrix
+    pyY = PyMatrix(prob['Y'], dtype=dtype)
+    out = []
+    for c in range(calls):
+        m = synth.initial_model(prob['Y'], prob['lag_set'], cfg['k'], seed=0)
+        t0 = time.perf_counter()
+        front.get_clib().train(pyY, m.lag_set, m.pyW, m.pyH, m.pylag_val, warm_start=True, max_iter=iters, missing=missing, **hyper)
+        wall = time.perf_counter() - t0
+        pr = session.train_profile(dtype) or {}
+        out.append({'wall_ms': 1e3 * wall, 'setup_ms': 1e3 * pr.get('setup_s', 0), 'upload_ms': 1e3 * pr.get('upload_s', 0),
+                    'compute_ms': 1e3 * pr.get('compute_s', 0), 'download_ms': 1e3 * pr.get('download_s', 0),
+                    'teardown_ms': 1e3 * pr.get('teardown_s', 0), 'bytes_h2d': pr.get('bytes_h2d'), 'bytes_d2h': pr.get('bytes_d2h'),
+                    'device_mallocs': pr.get('device_mallocs'), 'failed': pr.get('failed')})
+    steady = min(out[1:], key=lambda r: r['wall_ms']) if len(out) > 1 else out[0]
+    return {'entry': 'c_trmf_train(max_iter={})'.format(iters), 'first_call_after_session': out[0], 'steady': steady, 'calls': out,
+            'non_compute_ms_steady': steady['wall_ms'] - steady['compute_ms'],
+            'pcie_floor_ms': (steady['bytes_h2d'] or 0) / 56e9 * 1e3,
+            'note': 'wall clock around the C entry on host (NumPy) arrays; PyMatrix construction (the Python wrapper\'s CSR/CSC conversion) is outside'}
 
 
 def main():
@@ -182,6 +244,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'persist', 'shard'],
                     help='multi-GPU CG form (sets TRMF_CG; default: the library measures replicated vs time-sharded)')
+    ap.add_argument('--no-one-shot', action='store_true', help='skip the c_trmf_train (upload + train + download) leg')
+    ap.add_argument('--one-shot-iters', type=int, default=10)
     ap.add_argument('--cpu-iters', type=int, default=10)
     ap.add_argument('--cpu-threads', type=int, default=0)
     ap.add_argument('--cpu-state', default='', help=argparse.SUPPRESS)
@@ -278,10 +342,16 @@ def main():
             s_w.run(args.warmup).download()
         state_file = os.path.join(tempfile.gettempdir(), 'trmf_bench_state_{}.npz'.format(os.getpid()))
         np.savez(state_file, W=m_w.W, H=m_w.H, lag_val=m_w.lag_val)
+    one_shot = None
+    if rank == 0 and world == 1 and not args.no_one_shot:
+        one_shot = measure_one_shot(prob, cfg, hyper, missing, dtype, args.one_shot_iters)
     st = s.stats(args.steps)
     described = s.describe()          # which phases are sharded / which CG form the measure-once rule chose (set-up iterations, untimed)
     bytes_f = s.fsolve_bytes()
     ms_fk = float(np.mean([x['ms_F_kernel'] for x in st]))
+    ms_xg = float(np.mean([x['ms_X_gram'] for x in st]))
+    ms_x = float(np.mean([x['ms_X'] for x in st]))
+    cg_steps = float(np.mean([x['cg_iter'] for x in st]))
     s.download()
     s.close()
 
@@ -316,7 +386,9 @@ def main():
             'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_mfma_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
-                         'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows'},
+                         'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows',
+                         'traffic_source': None if traffic is None else 'profiles/fsolve_traffic.json: a PMC pass of this kernel taken by the builder on the '
+                                           'same sources (digest-guarded), NOT measured by this run; achieved / avg_kernel_ms are this run\'s HIP events'},
             # the same launch priced in arithmetic (one rank only): upper triangle of the k x k Gram + rhs per observed entry,
             # k^3/3 + 2 k^2 per system; fp64's MFMA pipe issues one v_mfma_f64_16x16x4 per ~100 cycles per SIMD on this chip
             # (profiles/r03_f64_pipe_ubench.txt) -- config 5's F-solve is bound by THAT, not by HBM
@@ -326,6 +398,8 @@ def main():
                 'algorithmic_flops_per_launch': fl, 'flop_model': 'nnz*(k*(k+1) + 2*k) + rows*(k^3/3 + 2*k^2); padded MFMA tiles are not counted'})(
                     float(nnz) * (cfg['k'] * (cfg['k'] + 1) + 2 * cfg['k']) + float(cfg['n']) * (cfg['k'] ** 3 / 3.0 + 2.0 * cfg['k'] ** 2),
                     157.3 if dtype == np.float32 else 78.6, 155.0 if dtype == np.float32 else 50.3),
+            'roofline_x': roofline_x(cfg, nnz, dtype, missing, world, ms_xg, ms_x, cg_steps, described),
+            'one_shot': one_shot,
             'phases_ms': {'F': float(np.mean([x['ms_F'] for x in st])), 'X': float(np.mean([x['ms_X'] for x in st])),
                           'Theta': float(np.mean([x['ms_LV'] for x in st])),
                           'cg_iter': [int(x['cg_iter']) for x in st]},

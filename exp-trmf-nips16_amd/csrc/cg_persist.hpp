@@ -30,6 +30,11 @@
 // arenas), and every rank polls its own copies.  All ranks sum all records in the single-GPU order: bit-identical iterates for
 // any number of ranks, one kernel per solve per rank, no launch, no collective and no host involvement inside the solve.
 //
+// Across launches (SHARD): exchange 0 of launch N + 1 stores into the parity-0 slots a slower peer may still be polling for the
+// last exchange of launch N.  Nothing in this file orders that: the host does -- xsolve_persist() ends with the all-gather of W
+// (a collective every rank enters only after its kernel has finished), so no rank launches solve N + 1 before every rank has
+// left solve N.  On one GPU consecutive launches are ordered by the stream.
+//
 // Same tiles, same per-thread element mapping, same arithmetic and summation order as hv_tile_kernel / cg_close_kernel /
 // accept_tile_kernel: the iterates are BIT-IDENTICAL to the launch-per-step path (tests/test_gpu_parity.py compares them).
 // Needs every workgroup co-resident (the host checks the grid against the occupancy the runtime reports; a plain launch has the
@@ -67,7 +72,10 @@ struct PersistArgs {
     unsigned long long *peer_hll[kMaxPeers];
     long long timeout_ticks;       // bound of every poll (100 MHz ticks; kPersistTimeoutTicks unless TRMF_PERSIST_TIMEOUT_MS says otherwise)
     long long *prof;               // -DTRMF_PERSIST_PROF builds only: cycle stamps of the phases (tile 0 and the middle tile)
+    int fail_tile, fail_x;         // test hook (TRMF_TEST + TRMF_PERSIST_FAIL=tile:exchange): that tile never publishes its record of
+                                   // that exchange (-2: of the final one, the acceptance test's) -- every workgroup's poll runs into its bound
 };
+constexpr int kFailFinal = -2;
 constexpr int kProfSlots = 8, kProfIters = 32;
 
 constexpr int kPersistMaxTiles = 512;                 // 32 poll chunks of 16 records (one bit each); also the co-residency ceiling of the chip
@@ -140,6 +148,9 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     int *lags = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
     double *recs = reinterpret_cast<double *>(hv_smem + (((size_t)(reinterpret_cast<unsigned char *>(lags + nlag) - hv_smem) + 15) / 16 * 16));   // [tiles][4]
     if (tid == 0) s_fail = 0;
+    // an earlier solve of this session ran into a poll bound: the iterates are void until the host has recovered (session.hpp,
+    // persist_recover); do not spend another bound per queued solve
+    if (__hip_atomic_load(&st->p2p_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
 #if defined(TRMF_PERSIST_PROF)
     const int prof_sel = blockIdx.x == 0 ? 0 : (int)blockIdx.x == (int)gridDim.x / 2 ? 1 : -1;
     auto stamp = [&](int iter, int slot) {
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     const bool ar_on = nlag > 0 && p.lambdaAR > 0;
 
     // ---- exchange: publish this tile's record of exchange x, collect everybody's ----
-    auto publish = [&](int x, double v0, double v1, double v2, double v3) {       // thread 0, after the tile's sc1 stores have been waited for
+    auto publish = [&](int x, double v0, double v1, double v2, double v3, bool final_x = false) {       // thread 0, after the tile's sc1 stores have been waited for
+        if (a.fail_tile == tile && a.fail_x == (final_x ? kFailFinal : x)) return;    // test hook: this record never arrives
         const size_t ri = ((size_t)(x & 1) * nbt + tile) * kLLWords;
         const unsigned long long tag = (unsigned long long)(a.epoch0 + (uint32_t)x) << 32;
         const double v[4] = {v0, v1, v2, v3};
@@ -242,11 +254,12 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     // Collect exchange x: the records of ALL tiles -> LDS, and (halo) the midx rows on either side of the tile -> dst_staged.
     // Every thread polling every record (the first version) put ~100k pollers on the memory system and an exchange took 10 us
     // (profiles/r04_persist_notes.txt); now
-    //   wave 0 polls the records: four lanes read the four 16-byte quarters of a record -- a wavefront load is 16 whole records,
-    //     1 KB contiguous -- and a quarter that carries the tag is parked in LDS at once (it validates itself); a chunk of 16
-    //     records is re-read only until all of its quarters have arrived;
-    //   waves 1-3 poll the tagged halo rows (a few 16-byte units per lane, all requested before the first check);
-    // both polls run side by side, so an exchange costs one store-to-load latency through memory, not a chain of them.
+    //   records: wave w owns the chunks w, w + 4, ... of 16 records; four lanes read the four 16-byte quarters of a record -- a
+    //     wavefront load is 16 whole records, 1 KB contiguous -- and a quarter that carries the tag is parked in LDS at once (it
+    //     validates itself); a chunk is re-read only until all of its quarters have arrived;
+    //   halo rows: every thread polls a few 16-byte units of the tagged rows, all requested before the first check;
+    // every wave does both in the same pass (requests of both first, then the checks), so an exchange costs one store-to-load
+    // latency through memory, not a chain of them.
     // Then every thread sums the records in hv_tile_kernel's order (thread t adds records t, t + 256, ...; fixed-order block
     // sums).  Returns false when a poll timed out (the whole grid then winds down).
     constexpr int EB = 2 * (int)sizeof(real), PER = 16 / EB;                  // tagged vector rows: bytes per element, elements per 16-byte unit
@@ -547,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         if (tid == 0) { keep[0] = f; keep[1] = sqrt((double)ggr); keep[2] = (double)ggr; }   // f, |g|, r^T r of the last completed iteration
     }
     double rho_prev_d = (double)ggr, rho_d = rho_prev_d;
+    if (lead) st->rho_hist[0] = rho_prev_d;                     // r^T r of iteration 0 = g^T g (the launch-per-step path stores it likewise)
     bool stopped = cg_stopped(ggr, cgtol);
     int stop_it = stopped ? 0 : kCgRunning, cg_iter = stopped ? 0 : 1;
 
@@ -608,7 +622,6 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         stamp(it + 1, 5);
         it++;
     }
-    if (lead && stop_it == 0) st->rho_hist[0] = rho_prev_d;
 
     // =========================== close the last completed iteration (cg_close_kernel) ===========================
     // s += alpha d, r' = r - alpha Hd (own rows; stop_it == 0: s = 0, r = -g), sums <g,s>, <s,r'>, <s,s>
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         rdir += rt * rt;
     });
     block_allsum3(sHs, rdir, unused3, smem);
-    if (tid == 0) publish(xi, rdir, 0, sHs, 0);
+    if (tid == 0) publish(xi, rdir, 0, sHs, 0, true);
     double ps[4];
     if (!collect(xi, 3, ps, false, nullptr)) return;
     const double gsr = (double)(real)keep[3], srr = (double)(real)keep[4];       // BLAS dots in val_type (rf_tron.h:186-187)

@@ -10,9 +10,9 @@
 // KP = 16*NT (zero padded), so every operand load is one 64-byte segment per 16-lane group and
 // needs no masking.
 //
-//   fsolve_kernel   one wavefront per item row: Gram in MFMA accumulators -> LDS -> one factor
-//                   column per lane in registers -> right-looking Cholesky with v_readlane
-//                   broadcasts -> forward/backward substitution -> row of F.  (trmf.cpp:369-397)
+//   fsolve_quad_kernel (fp32) / fsolve_mfma_kernel (fp64)   Gram + Cholesky + substitutions -> rows of F
+//                   (trmf.cpp:369-397).  Rounds 1-2's forms (one system per wavefront with one column per lane; an
+//                   8 x 8 lane grid) were removed in round 5; git history and profiles/r0[1-4]_* have them.
 //   gram_x_kernel   one wavefront per timestamp row: Gram + rhs of the X-side sub-problem, cached in
 //                   HBM for the CG (replaces the per-Hv re-streaming of trmf.cpp:269-288).
 //   loss_kernel     sum of squared residuals per timestamp row (trmf.cpp:231-245, loss part).
@@ -320,273 +320,19 @@ struct SingleRowStream {
     }
 };
 
-// ---- F-solve: one wavefront per item row (any element type; the fp64 path) ---------------------------
-// KMAX: static bound of the factorisation loops, k <= KMAX <= 16*NT (KMAX = k rounded up to 8).
 constexpr int kRingDepth = 4;      // groups per iteration of gram_ring (rows padded to a multiple)
 
-template <int NT, int KMAX>
-__global__ __launch_bounds__(256) void fsolve_kernel(const uint32_t *__restrict__ ptr,
-                                                     const uint32_t *__restrict__ idx,
-                                                     const real *__restrict__ val,
-                                                     const real *__restrict__ X,
-                                                     real *__restrict__ F, uint32_t row_begin,
-                                                     uint32_t row_end, int k, real lambda,
-                                                     uint32_t zero_row) {
-    constexpr int KP = kTile * NT, LD = KP + 1;
-    __shared__ real lds[4][KP * LD];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
-    if (row >= row_end) return;                         // wave-uniform; no block barrier below
-    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
-    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
-    if (p0 == p1) return;                               // trmf.cpp:374: empty rows stay untouched
-
-    GramState<NT> st;
-    st.clear();
-    real nowq[NT];
-#pragma unroll
-    for (int q = 0; q < NT; q++) nowq[q] = 0;
-    gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
-                                           SingleRowStream{4u * kRingDepth}, [](int) {});
-
-    const int g = lane >> 4, c = lane & 15;
-    // rhs: fold the 4 lane groups; afterwards lane t owns b[t] = st.b[t>>4]
-    real bz = 0;
-#pragma unroll
-    for (int q = 0; q < NT; q++) {
-        real v = st.b[q];
-        v += __shfl_xor(v, 16, kWave);
-        v += __shfl_xor(v, 32, kWave);
-        if (g == q) bz = v;
-    }
-
-    // accumulators -> LDS slab (upper tiles only)
-    real *S = lds[wave];
-    {
-        int t = 0;
-#pragma unroll
-        for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-            for (int tj = ti; tj < NT; tj++, t++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    S[(kTile * ti + Mfma16<real>::row(lane, r)) * LD + kTile * tj + c] = st.acc[t][r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // one column per lane: a[s] = A[s][col], valid for s <= col (upper triangle); + lambda on diag
-    const int col = lane < KP ? lane : KP - 1;
-    real a[KMAX];
-#pragma unroll
-    for (int s = 0; s < KMAX; s++) {
-        a[s] = S[s * LD + col];
-        if (s == lane) a[s] += lambda;                  // trmf.cpp:393
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // right-looking Cholesky A = U^T U, forward substitution fused (bz -> z = U^-T b)
-    real dinv = 0;
-#pragma unroll
-    for (int j = 0; j < KMAX; j++) {
-        if (j < k) {
-            const real inv = inv_sqrt(lane_bcast(a[j], j));
-            const real u = lane > j ? a[j] * inv : real(0);     // row j of U, strictly right of diag
-            const real zj = lane_bcast(bz, j) * inv;
-            bz = fma(-u, zj, bz);
-            if (lane == j) { bz = zj; dinv = inv; }
-            if (lane < KP) S[j * LD + col] = u;                 // row layout for the back solve
-#pragma unroll
-            for (int s = j + 1; s < KMAX; s++) a[s] = fma(-lane_bcast(u, s), u, a[s]);
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-
-    // one row of U per lane (a[t] = U[lane][t], t > lane), then column-oriented back substitution
-    const int rw = lane < KMAX ? lane : KMAX - 1;
-#pragma unroll
-    for (int t = 0; t < KMAX; t++) a[t] = S[rw * LD + t];
-    real x = 0;
-#pragma unroll
-    for (int t = KMAX - 1; t >= 0; t--) {
-        if (t < k) {
-            const real xt = lane_bcast(bz * dinv, t);
-            if (lane == t) x = xt;
-            bz = fma(-a[t], xt, bz);        // lanes >= t hold dead values from here on
-        }
-    }
-    if (lane < k) F[(size_t)row * KP + colpos(lane, NT)] = x;
-}
-
 #if !defined(TRMF_F32)
-// ---- F-solve, grid form (fp64): one wavefront per item row, the system block-cyclic over an 8 x 8 lane grid ----
-// fsolve_kernel above keeps one COLUMN of the k x k system per lane; every multiplier of the factorisation is
-// then a v_readlane pair feeding ONE fp64 FMA per lane, half the lanes idle below the diagonal, and at rank 64
-// the column costs 128 registers: ~3000 of its ~3500 instructions are the solve, and the rank-64 fp64 problem
-// of config 5 (1M systems per half-iteration, only ~50 observed entries each) is bound by it, not by the Gram.
-// Here lane (a, b) = (lane & 7, lane >> 3) holds A[8i+a][8l+b] for the block pairs i <= l -- 36 values at
-// rank 64, plus the right-hand side as one more block column on the lanes b == 0 -- so that
-//   * an elimination step updates every live entry with ONE FMA per register (no idle triangle beyond the
-//     8 x 8 granularity: 1248 FMAs per system instead of 2016 + as many broadcasts),
-//   * the two multipliers of an entry (pivot-row elements of its row class a and of its column class b) come
-//     out of a 64-double LDS line the eight lanes holding the pivot row write once per step (16-byte reads),
-//   * the factorisation is square-root free (A = L D L^T: A[s][t] -= A[j][s] A[j][t] / A[j][j]; the stored rows
-//     are D L^T, the pivots' reciprocals are kept) -- an fp64 rsqrt is a ~30-instruction sequence, the
-//     reciprocal is v_rcp_f64 + two Newton steps.  posv('U') of the reference (rf_matrix.h:3008-3014) and this
-//     differ by rounding only (fp64 gate 1e-6 on the factor rows, tests/test_gpu_parity.py),
-//   * the right-hand side is eliminated along with the matrix (forward substitution costs nothing extra) and the
-//     back substitution is column-oriented through the same LDS line: no cross-lane reductions anywhere.
-__device__ __forceinline__ double recip_newton(double d) {
-    double r = __builtin_amdgcn_rcp(d);
-    double e = fma(-d, r, 1.0);
-    r = fma(r, e, r);
-    e = fma(-d, r, 1.0);
-    return fma(r, e, r);
-}
 __device__ __forceinline__ void wave_lds_sync() {       // LDS operations of one wavefront retire in order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-#ifndef TRMF_GRID_WAVES
-#define TRMF_GRID_WAVES 3      // measured at config 5: 17.6 ms at 2 wavefronts per SIMD (198 VGPRs), 15.9 ms at 3 (168 VGPRs, 14 doubles of scratch)
 #endif
-constexpr int kGridTileLd = 20;     // doubles per row of the 16 x 16 staging tile: conflict-free for the (a, b) reads
 
-template <int NT, int KMAX>
-__global__ __launch_bounds__(256, TRMF_GRID_WAVES) void fsolve_grid_kernel(const uint32_t *__restrict__ ptr,
-                                                                          const uint32_t *__restrict__ idx,
-                                                                          const real *__restrict__ val,
-                                                                          const real *__restrict__ X,
-                                                                          real *__restrict__ F, uint32_t row_begin,
-                                                                          uint32_t row_end, int k, real lambda,
-                                                                          uint32_t zero_row) {
-    static_assert(sizeof(real) == 8, "grid F-solve is the fp64 path");
-    constexpr int KP = kTile * NT, NB = KMAX / 8, RS = NB + 2;       // RS: doubles per line row (even, >= NB + 1)
-    __shared__ __attribute__((aligned(16))) real tile_s[4][kTile * kGridTileLd];
-    __shared__ __attribute__((aligned(16))) real line_s[4][8 * RS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g = lane >> 4, c = lane & 15;             // MFMA view
-    const int a = lane & 7, b = lane >> 3;              // grid view: row class, column class
-    const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
-    if (row >= row_end) return;                         // wave-uniform; no block barrier below
-    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
-    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
-    if (p0 == p1) return;                               // trmf.cpp:374: empty rows stay untouched
-    real *tile = tile_s[wave], *line = line_s[wave];
-
-    real A[NB][NB + 1];                                 // A[i][l], i <= l < NB: block (i, l); A[i][NB]: rhs rows 8i+a (lanes b == 0)
-    {
-        GramState<NT> st;
-        st.clear();
-        real nowq[NT];
-#pragma unroll
-        for (int q = 0; q < NT; q++) nowq[q] = 0;
-        gram_ring<NT, kRingDepth, true, false>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
-                                               SingleRowStream{4u * kRingDepth}, [](int) {});
-        // rhs: fold the 4 lane groups, stage, pick up rows 8i + a
-#pragma unroll
-        for (int q = 0; q < NT; q++) {
-            real v = st.b[q];
-            v += __shfl_xor(v, 16, kWave);
-            v += __shfl_xor(v, 32, kWave);
-            if (g == 0) tile[kTile * q + c] = v;
-        }
-        wave_lds_sync();
-#pragma unroll
-        for (int i = 0; i < NB; i++) { const real v = tile[8 * i + a]; A[i][NB] = (b == 0) ? v : real(0); }
-        wave_lds_sync();
-        // accumulator tiles (row g + 4r, column c of tile (ti, tj)) -> staging tile -> the four blocks it covers
-        int t = 0;
-#pragma unroll
-        for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-            for (int tj = ti; tj < NT; tj++, t++) {
-                if (2 * tj < NB) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) tile[Mfma16<real>::row(lane, r) * kGridTileLd + c] = st.acc[t][r];
-                    wave_lds_sync();
-#pragma unroll
-                    for (int di = 0; di < 2; di++)
-#pragma unroll
-                        for (int dl = 0; dl < 2; dl++) {
-                            const int i = 2 * ti + di, l = 2 * tj + dl;
-                            if (i <= l && l < NB) A[i][l] = tile[(8 * di + a) * kGridTileLd + 8 * dl + b];
-                        }
-                    wave_lds_sync();
-                }
-            }
-    }
-#pragma unroll
-    for (int i = 0; i < NB; i++)                        // + lambda (trmf.cpp:393); pad rows: unit diagonal, their steps are no-ops
-        if (a == b) A[i][i] += (8 * i + a < k) ? lambda : real(1);
-
-    // ---- elimination: A = L D L^T, rhs carried as a column ----
-    static_for<KMAX>([&](auto J) {
-        constexpr int j = decltype(J)::value, ij = j >> 3, aj = j & 7;
-        const real invd = recip_newton(lane_bcast(A[ij][ij], 9 * aj));       // pivot: lane (aj, aj)
-        if (a == aj) {                                   // the eight lanes holding row j publish it: line[b][l] = A[j][8l+b]
-#pragma unroll
-            for (int l = ij; l <= NB; l++) line[b * RS + l] = A[ij][l];
-        }
-        wave_lds_sync();
-        real cv[NB], rv[NB];
-#pragma unroll
-        for (int l = ij; l < NB; l++) cv[l] = line[b * RS + l];              // A[j][8l + b]: multiplier of my columns
-        const real cr = line[NB];                                             // A[j][rhs] (line row 0)
-#pragma unroll
-        for (int i = ij; i < NB; i++) rv[i] = line[a * RS + i] * invd;        // A[j][8i + a] / A[j][j]: multiplier of my rows
-        if (a <= aj) rv[ij] = 0;                                              // rows <= j of block row ij are final
-        wave_lds_sync();
-#pragma unroll
-        for (int i = ij; i < NB; i++) {
-#pragma unroll
-            for (int l = i; l < NB; l++) A[i][l] = fma(-rv[i], cv[l], A[i][l]);
-            A[i][NB] = fma(-rv[i], cr, A[i][NB]);
-        }
-    });
-    // The pivots are the diagonal of the stored rows: d_{8i+a} = A[i][i] on lane (a, a).  Their reciprocals are
-    // formed once here and moved next to the rhs (lanes b == 0), where the back substitution needs them.
-    real dinv[NB];
-    if (a == b) {
-#pragma unroll
-        for (int i = 0; i < NB; i++) line[a * RS + i] = recip_newton(A[i][i]);
-    }
-    wave_lds_sync();
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        dinv[i] = line[a * RS + i];
-        if (a >= b) A[i][i] = 0;                        // diagonal blocks: keep only the strict upper part (s < t), so that a
-    }                                                   // column pushed to the rhs lanes never touches rows >= its own
-    wave_lds_sync();
-    // ---- back substitution (D L^T) x = y, column-oriented: x_j = y_j / d_j is formed on lane (aj, 0) and made
-    // wave-uniform, column j goes through the LDS line to the rhs lanes; row j's y is final from then on ----
-    static_for<KMAX>([&](auto Jr) {
-        constexpr int j = KMAX - 1 - decltype(Jr)::value, ij = j >> 3, aj = j & 7;
-        if constexpr (j > 0) {
-            const real xj = lane_bcast(A[ij][NB] * dinv[ij], aj);
-            if (b == aj) {
-#pragma unroll
-                for (int i = 0; i <= ij; i++) line[a * RS + i] = A[i][ij];        // A[8i + a][j]
-            }
-            wave_lds_sync();
-#pragma unroll
-            for (int i = 0; i <= ij; i++) A[i][NB] = fma(-line[a * RS + i], xj, A[i][NB]);   // meaningful on lanes b == 0
-            wave_lds_sync();
-        }
-    });
-    if (b == 0) {                                       // lane a holds x_{8i+a} = y / d for every block row i
-#pragma unroll
-        for (int i = 0; i < NB; i++)
-            if (8 * i + a < k) F[(size_t)row * KP + colpos(8 * i + a, NT)] = A[i][NB] * dinv[i];
-    }
-}
-#endif  // !TRMF_F32
 
 
 // ---- F-solve, fp64, factorisation IN the accumulator layout (round 3; config 5's kernel) --------------------------------
-// fsolve_grid_kernel moves the Gram out of the MFMA accumulators (LDS staging into an 8 x 8 lane grid) and eliminates
+// Round 2's kernel moved the Gram out of the MFMA accumulators (LDS staging into an 8 x 8 lane grid) and eliminated
 // one pivot at a time: 64 LDS round trips, ~1250 + 290 FMAs, 350 multiplies and 950 LDS instructions per rank-64
 // system.  Here the k x k system never leaves the registers the Gram was accumulated in:
 //
@@ -839,7 +585,7 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
 #if defined(TRMF_F32)
 // ---- F-solve, quad form (fp32): one wavefront per FOUR item rows ------------------------------------
 // The O(k^3) part of the solve is a chain of rank-1 updates whose operands must be broadcast across
-// lanes.  With one system per wavefront (fsolve_kernel above) every broadcast is a v_readlane that
+// lanes.  With one system per wavefront (round 1) every broadcast is a v_readlane that
 // feeds a single FMA per lane, and the kernel is VALU-issue bound (~3000 of its ~3500 instructions).
 // Here the four 16-lane rows of a wavefront each own one system: lane (grp, c) holds columns
 // {c, 16+c, 32+c, ...} of system `grp`, one ds_swizzle row-broadcast serves all four systems and
@@ -981,10 +727,8 @@ struct QuadStream {
 #endif
 // Four column tiles (rank 49..64) need more than the 168 registers of three wavefronts per SIMD: at that bound the <4,56> and
 // <4,64> instantiations spilled 296 / 460 bytes per lane; they are built for two wavefronts per SIMD instead.
-#ifndef TRMF_QUAD_WAVES4
-#define TRMF_QUAD_WAVES4 2      // (3 reproduces round 3's spilling build for the comparison in profiles/r04_fsolve_k64_fp32.txt)
-#endif
-constexpr int quad_waves(int NT) { return NT >= 4 ? TRMF_QUAD_WAVES4 : TRMF_QUAD_WAVES; }
+// (profiles/r04_fsolve_k64_fp32.txt has the comparison).
+constexpr int quad_waves(int NT) { return NT >= 4 ? 2 : TRMF_QUAD_WAVES; }
 template <int NT, int KMAX, int ABL = 0>
 __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,

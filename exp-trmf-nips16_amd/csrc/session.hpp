@@ -15,6 +15,7 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <initializer_list>
@@ -28,6 +29,7 @@
 #include "full_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "common.hpp"
+#include "device_pool.hpp"
 #include "gram_kernels.hpp"
 #include "resident_kernels.hpp"
 #include "theta_kernels.hpp"
@@ -51,17 +53,20 @@ struct FillStreamScope {
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0, cap = 0;       // elements in use / allocated (a buffer that shrinks or regrows within cap is reused)
+    DevicePool *pool = nullptr;  // where `p` came from (device_pool.hpp: slabs shared by the sessions of this process)
     DevBuf() {}
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; cap = 0; } }
-    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    void release() { if (p) { pool->free(p); p = nullptr; n = 0; cap = 0; } }
+    void swap(DevBuf &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); std::swap(pool, o.pool); }
     int alloc(size_t count, bool zero = true) {
         const size_t want = std::max<size_t>(count, 1);
         if (!p || want > cap) {
             release();
-            TRMF_HIP_CHECK(hipMalloc((void **)&p, want * sizeof(T)));
+            pool = &DevicePool::current();
+            p = static_cast<T *>(pool->alloc(want * sizeof(T)));
+            if (!p) { set_error("device allocation of " + std::to_string(want * sizeof(T)) + " bytes failed"); return kFail; }
             cap = want;
         }
         n = count;
@@ -74,9 +79,13 @@ template <typename T> struct DevBuf {
         }
         return 0;
     }
+    // Host array -> this buffer through the library's pinned ring (device_pool.hpp), ordered on the owning session's stream;
+    // returns once the SOURCE has been read (the caller's array may go away), not when the bytes have landed.
     int upload(const T *src, size_t count) {
         if (alloc(count, false)) return kFail;
-        if (count) TRMF_HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+        if (!count) return 0;
+        if (fill_stream()) return HostStager::current().h2d(p, src, count * sizeof(T), fill_stream());
+        TRMF_HIP_CHECK(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
         return 0;
     }
 };
@@ -86,7 +95,7 @@ struct DeviceIterLog {       // one per ALS iteration, filled on device
     XState x;
 };
 
-struct PhaseEvents { hipEvent_t f0, fk0, fk1, f1, x1, lv1; };
+struct PhaseEvents { hipEvent_t f0, fk0, fk1, f1, xg1, x1, lv1; };   // xg1: end of the X-side Gram build (start of the CG)
 
 struct TrmfSessionImpl {
     // problem
@@ -163,16 +172,23 @@ struct TrmfSessionImpl {
     XParams xp{};
 
     ~TrmfSessionImpl() {
+        // nothing of this session may still be running when its buffers go back to the pool and its stream to the cache
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (side) (void)hipStreamSynchronize(side);
         for (auto &e : events) {
-            hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.x1, e.lv1};
+            hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.xg1, e.x1, e.lv1};
             for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
         }
         for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2, ts0, ts1}) if (ev) (void)hipEventDestroy(ev);
         release_p2p();
         for (hipEvent_t ev : {ov_b, ov_c[0], ov_c[1], ov_c[2], ov_c[3]}) if (ev) (void)hipEventDestroy(ev);
         if (side) (void)hipStreamDestroy(side);
-        if (stream) (void)hipStreamDestroy(stream);
+        StreamCache::release(stream);
     }
+    // Knobs that exist for the tests and the measurement scripts (forced failures, forced forms, ablations) are read only when
+    // TRMF_TEST is set; INTEGRATION.md lists the production knobs.
+    static bool test_knobs() { static const bool on = getenv("TRMF_TEST") != nullptr; return on; }
+    static const char *test_env(const char *name) { return test_knobs() ? getenv(name) : nullptr; }
     void release_p2p() {
         for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
         p2p.peer.clear();
@@ -182,7 +198,7 @@ struct TrmfSessionImpl {
     }
     // test hook TRMF_P2P_FAIL=<stage>[:rank] (stage: alloc | export | open | fence): the set-up fails there (on that rank only)
     bool p2p_forced_failure(const char *stage) const {
-        const char *e = getenv("TRMF_P2P_FAIL");
+        const char *e = test_env("TRMF_P2P_FAIL");
         if (!e) return false;
         const std::string v(e);
         const size_t c = v.find(':');
@@ -298,14 +314,14 @@ struct TrmfSessionImpl {
     // Factors carry one extra all-zero row at index `rows` (operand of masked-out MFMA lanes).  The ABI's rows x k
     // arrays cross PCIe as they are; padding and column interleaving happen on the device (a host loop took 1.5 s for
     // the 512 MB item factor of config 5).
-    int upload_padded(DevBuf<real> &dst, const real *src, size_t rows) {
-        DevBuf<real> raw;
+    // `raw` (the unpadded copy) must stay alive until the pad kernel has run: a member of the session, released by
+    // finish_setup() after the set-up's one synchronisation.
+    int upload_padded(DevBuf<real> &dst, DevBuf<real> &raw, const real *src, size_t rows) {
         if (raw.upload(src, rows * (size_t)k) || dst.alloc((rows + 1) * (size_t)KP, false)) return kFail;
         const size_t N = (rows + 1) * (size_t)KP;
         hipLaunchKernelGGL(factor_pad_kernel, dim3((unsigned)std::min<size_t>(4096, (N + 255) / 256)), dim3(256), 0, stream,
                            raw.p, rows, k, KP, NT, dst.p);
         TRMF_HIP_CHECK(hipGetLastError());
-        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
     int download_padded(const DevBuf<real> &src, real *dst, size_t rows) {
@@ -320,35 +336,96 @@ struct TrmfSessionImpl {
         TRMF_HIP_CHECK(hipMemcpy(dst, raw.p, N * sizeof(real), hipMemcpyDeviceToHost));
         return 0;
     }
-    int upload_ptr32(DevBuf<uint32_t> &dst, const size_t *src, size_t count) {
-        DevBuf<uint64_t> wide;
-        if (wide.upload((const uint64_t *)src, count) || dst.alloc(count, false)) return kFail;
-        hipLaunchKernelGGL(narrow_ptr_kernel, dim3((unsigned)std::min<size_t>(1024, (count + 255) / 256)), dim3(256), 0, stream, wide.p, count, dst.p);
+    // All three factors -> host staging in one stream-ordered batch (pinned memory of the library when they fit, ordinary
+    // memory otherwise); nothing of the caller's is touched.  commit() then copies them out: c_trmf_train's outputs change
+    // together or not at all (the reference's contract for a failed call, trmf.cpp:632-634).
+    struct StagedFactors {
+        unsigned char *base = nullptr;
+        std::unique_lock<std::mutex> lease;
+        std::vector<unsigned char> fallback;
+        size_t bW = 0, bH = 0, bL = 0;
+        void commit(void *Wout, void *Hout, void *Lout) const {
+            HostStager::parallel_copy(Wout, base, bW);
+            HostStager::parallel_copy(Hout, base + bW, bH);
+            if (bL) std::memcpy(Lout, base + bW + bH, bL);
+        }
+    };
+    int download_staged(StagedFactors &sf) {
+        sf.bW = (size_t)T * k * sizeof(real); sf.bH = (size_t)n * k * sizeof(real); sf.bL = (size_t)nlag * k * sizeof(real);
+        const size_t total = sf.bW + sf.bH + sf.bL;
+        sf.base = HostStager::current().staging(total, sf.lease);
+        if (!sf.base) {
+            try { sf.fallback.resize(total); } catch (const std::bad_alloc &) { set_error("host staging of the factors: out of memory"); return kFail; }
+            sf.base = sf.fallback.data();
+        }
+        DevBuf<real> rawW, rawH;
+        if (rawW.alloc((size_t)T * k, false) || rawH.alloc((size_t)n * k, false)) return kFail;
+        auto unpad = [&](const DevBuf<real> &src, size_t rows, real *dst) {
+            const size_t N = rows * (size_t)k;
+            if (N) hipLaunchKernelGGL(factor_unpad_kernel, dim3((unsigned)std::min<size_t>(4096, (N + 255) / 256)), dim3(256), 0, stream, src.p, rows, k, KP, NT, dst);
+        };
+        unpad(W, T, rawW.p); unpad(H, n, rawH.p);
         TRMF_HIP_CHECK(hipGetLastError());
+        if (sf.bW) TRMF_HIP_CHECK(hipMemcpyAsync(sf.base, rawW.p, sf.bW, hipMemcpyDeviceToHost, stream));
+        if (sf.bH) TRMF_HIP_CHECK(hipMemcpyAsync(sf.base + sf.bW, rawH.p, sf.bH, hipMemcpyDeviceToHost, stream));
+        if (sf.bL) TRMF_HIP_CHECK(hipMemcpyAsync(sf.base + sf.bW + sf.bH, theta.p, sf.bL, hipMemcpyDeviceToHost, stream));
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        if (test_env("TRMF_FAIL_DOWNLOAD")) { set_error("download failure forced by TRMF_FAIL_DOWNLOAD"); return kFail; }   // test hook
         return 0;
     }
-    // sum of squares of a device value array, fp64 (fixed order)
-    int device_sum_squares(const real *dv, size_t count, double *out) {
-        const int nb = 1024;
-        DevBuf<double> part;
-        if (part.alloc(nb)) return kFail;
-        hipLaunchKernelGGL(sumsq_values_kernel, dim3(nb), dim3(256), 0, stream, dv, count, part.p);
+    // the ABI's 64-bit pointer arrays are narrowed on their way through the pinned ring (nnz < 2^32 is checked at the boundary)
+    int upload_ptr32(DevBuf<uint32_t> &dst, const size_t *src, size_t count) {
+        if (dst.alloc(count, false)) return kFail;
+        return HostStager::current().h2d_narrow(dst.p, (const uint64_t *)src, count, stream);
+    }
+    // sum of squares of a device value array, fp64 (fixed order): the kernel is enqueued here, the partial sums are read by
+    // finish_sum_squares() after the caller's next synchronisation of the stream
+    static constexpr int kSumsqBlocks = 1024;
+    DevBuf<double> sumsq_part;
+    int launch_sum_squares(const real *dv, size_t count) {
+        if (sumsq_part.alloc(kSumsqBlocks)) return kFail;
+        hipLaunchKernelGGL(sumsq_values_kernel, dim3(kSumsqBlocks), dim3(256), 0, stream, dv, count, sumsq_part.p);
         TRMF_HIP_CHECK(hipGetLastError());
-        std::vector<double> h(nb);
+        return 0;
+    }
+    int finish_sum_squares(double *out) {
+        std::vector<double> h(kSumsqBlocks);
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
-        TRMF_HIP_CHECK(hipMemcpy(h.data(), part.p, nb * sizeof(double), hipMemcpyDeviceToHost));
+        TRMF_HIP_CHECK(hipMemcpy(h.data(), sumsq_part.p, kSumsqBlocks * sizeof(double), hipMemcpyDeviceToHost));
         double acc = 0;
         for (double x : h) acc += x;
         *out = acc;
         return 0;
     }
+    int device_sum_squares(const real *dv, size_t count, double *out) { return launch_sum_squares(dv, count) || finish_sum_squares(out) ? kFail : 0; }
 
     // Host copies of the two pointer arrays (8 bytes per row/column): row partitions, the byte model of
     // fsolve_bytes(), and the merged pointers of append_rows() are derived from them.
     std::vector<uint64_t> host_row_ptr, host_col_ptr;
     double ysq_acc = 0;          // sum of y^2 over every entry uploaded so far (fp64)
 
+    // ---- set-up (trmf_session_create; the first part of every c_trmf_train call) ----------------------------------------
+    // Everything is enqueued on the session's stream and the host waits ONCE, at the end: the caller's arrays travel through the
+    // library's pinned ring (device_pool.hpp), the 64-bit pointers are narrowed on the way, the factors are padded / interleaved
+    // and sum y^2 is formed on the device; device memory comes from the process-level pool, the stream from the stream cache.
+    // Round 4 took 0.12 s for config 3 here (a hipMalloc + a synchronous pageable hipMemcpy per array, ~10 stream
+    // synchronisations, ~30 hipFree at the end); profiles/r05_oneshot.txt has the split now.
+    double t_upload_s = 0;       // seconds of create() spent reading the caller's arrays (TrmfTrainProfile.upload_s)
+    double bytes_uploaded = 0;
+    DevBuf<real> raw_W, raw_H;   // unpadded factor uploads: alive until the set-up's synchronisation
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    size_t footprint_estimate() const {
+        const size_t sz = sizeof(real), NVb = (size_t)(T + 1) * KP * sz, NHb = (size_t)(n + 1) * KP * sz;
+        size_t b = dense ? 2 * (size_t)T * n * sz + (full ? (size_t)kGemmChunks * std::max(T, n) * KP * sz : 0)
+                         : 2 * (size_t)nnz * (4 + sz) + ((size_t)T + n + 2) * 4;
+        b += NVb + NHb + (size_t)(T + n) * k * sz;              // factors and their unpadded upload copies
+        b += 11 * NVb + 4 * NVb;                                 // CG vectors, rhs; tagged rows of the persistent kernel
+        if (!full) b += (size_t)T * k * k * sz;                  // Gram cache (packed on the unfused path: an upper bound)
+        if (full) b += NHb;
+        if (generic) b += (size_t)std::min(kGenBlocks, std::max(n, 1)) * k * k * sz;
+        b += (size_t)kLogCap * sizeof(DeviceIterLog) + ((size_t)32 << 20);
+        return b + b / 16;
+    }
     int create(const PyMatrix *Y, const uint32_t *lags, uint32_t lag_size, const PyMatrix *Wm,
                const PyMatrix *Hm, const PyMatrix *LVm) {
         T = (int)Y->rows; n = (int)Y->cols; k = (int)Wm->cols; nnz = Y->nnz;
@@ -356,43 +433,48 @@ struct TrmfSessionImpl {
         generic = k > kMaxRank;
         nlag = (int)lag_size; midx = nlag ? (int)lags[nlag - 1] : 0;
         comm = active_comm();
-        if (const char *e = getenv("TRMF_FSOLVE")) {
-            const std::string m(e);
-            use_quad = use_quad && m != "wave";
-            if (sizeof(real) == 8) { use_mfma = m != "wave" && m != "grid"; use_grid = m == "grid"; }
-        }
-        if (const char *e = getenv("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
-        TRMF_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        if (const char *e = test_env("TRMF_DEBUG_ABLATE")) dbg_flags = atoi(e);
+        if (StreamCache::acquire(&stream)) return kFail;
         FillStreamScope fill(stream);
-
         dense = Y->type != TRMF_SPARSE;
+        DevicePool::current().reserve(footprint_estimate());
+
+        const double tu0 = now_s();
         if (!dense) {
             host_row_ptr.assign(Y->row_ptr, Y->row_ptr + (size_t)T + 1);
             host_col_ptr.assign(Y->col_ptr, Y->col_ptr + (size_t)n + 1);
+            // both orientations cross PCIe as the caller holds them: the CSC's entry order IS the F-solve's summation order
+            // (the reference's, trmf.cpp:369-397), and a caller's arrays need not be the canonical transpose of its CSR (the
+            // reference's own coo path keeps duplicate entries apart, rf_util.py:98-118) -- deriving one orientation from the
+            // other on the device would save 80 MB = 1.7 ms of the ring's time at config 3 and give up that guarantee
+            if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;      // CSC first: the first F-solve needs it
+            if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
+            if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
             if (upload_ptr32(Yr_ptr, Y->row_ptr, (size_t)T + 1)) return kFail;
             if (Yr_idx.upload(Y->col_idx, nnz)) return kFail;
             if (Yr_val.upload((const real *)Y->val_t, nnz)) return kFail;
-            if (upload_ptr32(Yc_ptr, Y->col_ptr, (size_t)n + 1)) return kFail;
-            if (Yc_idx.upload(Y->row_idx, nnz)) return kFail;
-            if (Yc_val.upload((const real *)Y->val, nnz)) return kFail;
-            if (device_sum_squares(Yr_val.p, nnz, &ysq_acc)) return kFail;
+            if (launch_sum_squares(Yr_val.p, nnz)) return kFail;
+            bytes_uploaded += 2.0 * (double)nnz * (4 + sizeof(real)) + 8.0 * ((double)T + n + 2);
         } else {
             // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC
             std::vector<real> tn;
             ysq_acc = dense_rows_to_rowmajor(Y, tn);
             if (Yd_tn.upload(tn.data(), tn.size()) || Yd_nt.alloc((size_t)T * n, false)) return kFail;
             launch_transpose(Yd_tn.p, T, n, Yd_nt.p);
+            bytes_uploaded += (double)tn.size() * sizeof(real);
         }
-        set_trYTY();
         if (lag_set.upload(lags, nlag)) return kFail;
         {
             const std::vector<uint32_t> steps = ar_lag_steps(lags, nlag);
             nsteps = (int)steps.size();
             if (lag_steps.upload(steps.data(), steps.size())) return kFail;
         }
-        if (upload_padded(W, (const real *)Wm->val, T)) return kFail;
-        if (upload_padded(H, (const real *)Hm->val, n)) return kFail;
+        if (upload_padded(W, raw_W, (const real *)Wm->val, T)) return kFail;
+        if (upload_padded(H, raw_H, (const real *)Hm->val, n)) return kFail;
         if (theta.upload((const real *)LVm->val, (size_t)nlag * k)) return kFail;
+        bytes_uploaded += ((double)T + n + nlag) * k * sizeof(real);
+        t_upload_s = now_s() - tu0;
+
         if (xstate.alloc(1) || log.alloc(kLogCap)) return kFail;
         if (full && (Bf.alloc((size_t)n * KP) || GSf.alloc((size_t)k * k) || Uf.alloc((size_t)k * k) || GSx.alloc((size_t)k * k + kHvGramPad) ||
                      sgram_part.alloc((size_t)kSmallGramBlocks * k * k)))
@@ -402,15 +484,19 @@ struct TrmfSessionImpl {
 
         events.resize(kEventRing);
         for (auto &e : events) {
-            hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.x1, &e.lv1};
+            hipEvent_t *all[] = {&e.f0, &e.fk0, &e.fk1, &e.f1, &e.xg1, &e.x1, &e.lv1};
             for (hipEvent_t *ev : all) { *ev = nullptr; TRMF_HIP_CHECK(hipEventCreate(ev)); }
         }
         for (hipEvent_t *ev : {&gx0, &gx1, &gx2, &fs0, &fs1, &fs2, &ts0, &ts1}) TRMF_HIP_CHECK(hipEventCreate(ev));
         if (gramx_times.alloc((size_t)8 * comm->world)) return kFail;
         if (comm->world == 1) { gramx_mode = kGramxShard; fs_mode = kShardOn; }     // nothing to decide
-        if (const char *e = getenv("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
-        if (const char *e = getenv("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
-        TRMF_HIP_CHECK(hipDeviceSynchronize());
+        if (const char *e = test_env("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
+        if (const char *e = test_env("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
+        // the set-up's one synchronisation: uploads landed, factors padded, sum y^2 formed
+        if (!dense) { if (finish_sum_squares(&ysq_acc)) return kFail; }
+        else TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        set_trYTY();
+        raw_W.release(); raw_H.release(); sumsq_part.release();
         if (comm->world > 1) {
             // one small gather now: the communicator's connections are set up before the ALS loop (and before the timed
             // gathers of the shard decisions).  The values are this rank's own zeros, the buffer is rewritten before use.
@@ -490,20 +576,20 @@ struct TrmfSessionImpl {
             }
             if (rc) return kFail;
         }
-        tile_TI = 0; nbt = 1; persist_state = 0; persist_shard_state = 0; persist_failed = false; persist_note.clear();
+        tile_TI = 0; nbt = 1; persist_state = 0; persist_shard_state = 0; persist_failed = false; persist_note.clear(); snap_iter = -1;
         {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
             int TI = hv_tile_rows(k);
-            if (const char *e = getenv("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
+            if (const char *e = test_env("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
             // the tile kernel addresses the CG vectors with 32-bit byte offsets through buffer descriptors
             const bool fits32 = (uint64_t)(T + 1) * KP * sizeof(real) < 0x7fffffffull;
-            if (!generic && fits32 && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !getenv("TRMF_NO_HV_TILE")) {
+            if (!generic && fits32 && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !test_env("TRMF_NO_HV_TILE")) {
                 tile_TI = TI;
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
             }
         }
         // The cached Grams: k x k per timestamp for the fused kernel; the unfused path's product streams them once per CG
         // step and nothing else (1.64 GB per step at config 5), so there only the upper triangle is kept (packed_gram_elems)
-        gpacked = !full && !generic && tile_TI == 0 && !getenv("TRMF_GRAM_FULL");
+        gpacked = !full && !generic && tile_TI == 0 && !test_env("TRMF_GRAM_FULL");
         const size_t gelems = gpacked ? packed_gram_elems(k) : (size_t)k * k;
         if (G.alloc((full ? 1 : (size_t)T * gelems) + kHvGramPad)) return kFail;
         if (gpacked) {
@@ -535,7 +621,7 @@ struct TrmfSessionImpl {
                 const double cost = (double)((tiles * groups + cus - 1) / cus) * (3.0 * ti + 3.0 * midx + 2000);
                 if (best == 0 || cost < best) { best = cost; ar_TI = ti; }
             }
-            if (const char *e = getenv("TRMF_AR_TI")) ar_TI = std::max(kArU, atoi(e) / kArU * kArU);   // experiments
+            if (const char *e = test_env("TRMF_AR_TI")) ar_TI = std::max(kArU, atoi(e) / kArU * kArU);   // experiments
             const size_t need = ar_tile_lds_bytes(ar_TI, midx, nlag);
             if (allow_dyn_lds(ar_tile_kernel<AR_PLAIN>, need, "AR operator (max lag too large)") ||
                 allow_dyn_lds(ar_tile_kernel<AR_CG_STEP>, need, "AR operator (max lag too large)"))
@@ -626,7 +712,7 @@ struct TrmfSessionImpl {
         // the persistent kernel across ranks: measured in the set-up iterations only (a trial that times out -- workgroups of several
         // ranks that share ONE device and do not fit together -- costs the iteration it ran in, which autotune() undoes)
         const char *at = getenv("TRMF_AUTOTUNE");
-        if (fused_ts && p2p.on && !(at && atoi(at) == 0) && !getenv("TRMF_NO_PERSIST_SHARD") && persist_usable_shard()) {
+        if (fused_ts && p2p.on && !(at && atoi(at) == 0) && !test_env("TRMF_NO_PERSIST_SHARD") && persist_usable_shard()) {
             if (max_ranks_per_device == 1) x_cands.push_back(kXTsPersist);
             else persist_note = std::to_string(max_ranks_per_device) + " ranks share one device: the persistent-kernel form is not tried";
         }
@@ -762,7 +848,7 @@ struct TrmfSessionImpl {
         if (dense && has_transform && apply_series_transform()) return kFail;   // current coefficients over the grown raw matrix
         set_trYTY();
         iter = 0;
-        if (gramx_mode != kGramxReplicate && comm->world > 1 && !getenv("TRMF_GRAMX")) { gramx_mode = kGramxMeasure; gramx_calls = 0; }
+        if (gramx_mode != kGramxReplicate && comm->world > 1 && !test_env("TRMF_GRAMX")) { gramx_mode = kGramxMeasure; gramx_calls = 0; }
         if (alloc_time_scratch()) return kFail;
         TRMF_HIP_CHECK(hipDeviceSynchronize());
         return autotune();
@@ -777,22 +863,6 @@ struct TrmfSessionImpl {
     }
 
     // ---- F-solve (trmf.cpp:654-663 -> 369-397) -------------------------------------------------------
-    template <int NT_, int KMAX_> int launch_fsolve(uint32_t rb, uint32_t re) {
-        const uint32_t rows = re - rb;
-        if (rows == 0) return 0;
-        hipLaunchKernelGGL((fsolve_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
-                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
-        return 0;
-    }
-    template <int NT_, int KMAX_> int launch_fsolve_grid(uint32_t rb, uint32_t re) {
-        const uint32_t rows = re - rb;
-        if (rows == 0) return 0;
-#if !defined(TRMF_F32)
-        hipLaunchKernelGGL((fsolve_grid_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
-                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
-#endif
-        return 0;
-    }
     template <int NT_, int KMAX_> int launch_fsolve_mfma(uint32_t rb, uint32_t re) {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
@@ -828,9 +898,7 @@ struct TrmfSessionImpl {
         return 0;
     }
     // fp32: four systems per wavefront (fsolve_quad_kernel); fp64: one system per wavefront, factorised in the MFMA
-    // accumulator layout (fsolve_mfma_kernel).  TRMF_FSOLVE=grid: the round-2 fp64 kernel (block-cyclic over an 8 x 8
-    // lane grid); TRMF_FSOLVE=wave: one system per wavefront, one column per lane
-    bool use_quad = sizeof(real) == 4, use_grid = false, use_mfma = sizeof(real) == 8;
+    // accumulator layout (fsolve_mfma_kernel)
     // X-side Gram build across ranks: sharded rows + all-gather of G (64 MB at config 3) pays only when a
     // rank's share of the gather is cheaper than the rows it no longer computes -- true on 8 GPUs, not on 2.
     // First call measures (kernel and gather time of every rank, exchanged through the communicator so that
@@ -859,10 +927,8 @@ struct TrmfSessionImpl {
             case 64: FN<4, 64>(rb, re); break;                                       \
             default: set_error("unsupported rank"); return kFail;                    \
         }
-        if (use_quad) { TRMF_FSOLVE_SWITCH(launch_fsolve_quad) }
-        else if (use_mfma) { TRMF_FSOLVE_SWITCH(launch_fsolve_mfma) }
-        else if (use_grid) { TRMF_FSOLVE_SWITCH(launch_fsolve_grid) }
-        else { TRMF_FSOLVE_SWITCH(launch_fsolve) }
+        if (sizeof(real) == 4) { TRMF_FSOLVE_SWITCH(launch_fsolve_quad) }
+        else { TRMF_FSOLVE_SWITCH(launch_fsolve_mfma) }
 #undef TRMF_FSOLVE_SWITCH
         return 0;
     }
@@ -913,11 +979,11 @@ struct TrmfSessionImpl {
     // between the ranks of an nnz-balanced partition (near 16 / 48 / 64 MiB the ranks disagreed).
     int overlap_chunks() {
         if (comm->world <= 1 || full || host_col_ptr.empty()) return 0;
-        if (const char *e = getenv("TRMF_FOVERLAP")) { const int c = atoi(e); return c <= 0 ? 0 : std::max(2, std::min(kMaxChunks, c)); }
+        if (const char *e = test_env("TRMF_FOVERLAP")) { const int c = atoi(e); return c <= 0 ? 0 : std::max(2, std::min(kMaxChunks, c)); }
         uint64_t rows = 0;
         for (int r = 0; r < comm->world; r++) rows = std::max<uint64_t>(rows, fbounds[r + 1] - fbounds[r]);
         uint64_t thresh = kOverlapBytes;
-        if (const char *e = getenv("TRMF_FOVERLAP_BYTES")) thresh = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests: the threshold at small sizes
+        if (const char *e = test_env("TRMF_FOVERLAP_BYTES")) thresh = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests: the threshold at small sizes
         const uint64_t bytes = rows * KP * sizeof(real);
         return bytes >= thresh ? (int)std::max<uint64_t>(2, std::min<uint64_t>(kMaxChunks, bytes / thresh)) : 0;
     }
@@ -1157,7 +1223,7 @@ struct TrmfSessionImpl {
                                H.p + (size_t)rb * KP, nrows, k, KP, NT);
         } else if (re > rb) {
             const size_t ulds = (size_t)k * k * sizeof(real);          // <= 32 KB
-            if (getenv("TRMF_CHOL_WORKGROUP")) hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
+            if (test_env("TRMF_CHOL_WORKGROUP")) hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
             else switch (NT) {
                 case 1: hipLaunchKernelGGL(chol_wave_kernel<1>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
                 case 2: hipLaunchKernelGGL(chol_wave_kernel<2>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
@@ -1390,7 +1456,9 @@ struct TrmfSessionImpl {
 #define TRMF_PERSIST_PREP_S(KQV) slots = persist_prepare<KQV, true>(lds)
                 TRMF_PERSIST_SWITCH(TRMF_PERSIST_PREP_S)
 #undef TRMF_PERSIST_PREP_S
-                if (slots >= tsh_rank.ntiles) persist_shard_state = 1;
+                // against the LARGEST block of the partition (the last rank may own fewer tiles): every rank must reach the same
+                // answer, or the ranks' candidate lists -- and with them the collectives of decide_x_form() -- differ
+                if (slots >= tsh_rank.tpr) persist_shard_state = 1;
             }
         }
         return persist_shard_state == 1;
@@ -1413,9 +1481,14 @@ struct TrmfSessionImpl {
         pa.timeout_ticks = kPersistTimeoutTicks;
         if (const char *e = getenv("TRMF_PERSIST_TIMEOUT_MS")) pa.timeout_ticks = std::max(1ll, atoll(e)) * 100000ll;
         pa.epoch0 = persist_epoch; pa.TI = tile_TI; pa.maxcg = maxcg; pa.log_x = log_x; pa.log_n = log_n;
+        pa.fail_tile = -1; pa.fail_x = -1;
+        if (const char *e = test_env("TRMF_PERSIST_FAIL")) {           // "<tile>:<exchange>" (exchange -2: the final one)
+            pa.fail_tile = atoi(e);
+            if (const char *c = strchr(e, ':')) pa.fail_x = atoi(c + 1);
+        }
         persist_epoch += (uint32_t)maxcg + 8;
 #if defined(TRMF_PERSIST_PROF)
-        if (getenv("TRMF_PERSIST_PROF")) {
+        if (test_env("TRMF_PERSIST_PROF")) {
             if (!persist_prof.p && persist_prof.alloc((size_t)2 * kProfIters * kProfSlots + 2 * (size_t)kPersistMaxTiles)) return kFail;
             pa.prof = persist_prof.p;
         }
@@ -1424,7 +1497,9 @@ struct TrmfSessionImpl {
 #define TRMF_PERSIST_GO(KQV) if (shard ? persist_launch<KQV, true>(pa, lds) : persist_launch<KQV, false>(pa, lds)) return kFail
         TRMF_PERSIST_SWITCH(TRMF_PERSIST_GO)
 #undef TRMF_PERSIST_GO
-        if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
+        // the F-solve gathers rows of all of W -- and this collective is what keeps a fast rank's next solve out of the record
+        // slots a slow rank is still polling (cg_persist.hpp, "Across launches")
+        if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;
         return 0;
     }
 #undef TRMF_PERSIST_SWITCH
@@ -1607,7 +1682,7 @@ struct TrmfSessionImpl {
                 hipLaunchKernelGGL(apply_kernel<false>, dim3(blocks), dim3(256), ap_lds, stream, xp, st, cg_it, operand, resid, arbase.p,
                                    Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), rpb, row_b, rows, slot_b);
         };
-        if (full && !generic && !getenv("TRMF_NO_APPLY_SHARED")) {       // one Gram for every timestamp: the product runs on the matrix pipe (never sharded)
+        if (full && !generic && !test_env("TRMF_NO_APPLY_SHARED")) {       // one Gram for every timestamp: the product runs on the matrix pipe (never sharded)
 #define TRMF_LAUNCH_APPLY_SHARED(NTV)                                                                                           \
     hipLaunchKernelGGL((apply_shared_mfma_kernel<NTV>), dim3(nba), dim3(256), apply_shared_lds_bytes(KP), stream, xp, st, cg_it,  \
                        operand, resid, arbase.p, Gmat(), Bv.p, minus_b, out, dot_mode, P(P_DOT), 0, T, 0)
@@ -1655,6 +1730,7 @@ struct TrmfSessionImpl {
     }
     const real *Gmat() const { return full ? GSx.p : G.p; }      // shared H^T H or the per-timestamp cache
 
+    hipEvent_t xg1_event = nullptr;           // this iteration's PhaseEvents::xg1 (set by run())
     int xsolve(XState *log_x = nullptr, double *log_n = nullptr) {   // log_*: record written by the accept kernel
         XState *st = xstate.p;
         const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);   // trmf.cpp:523-526
@@ -1680,6 +1756,7 @@ struct TrmfSessionImpl {
         } else {
             if (gram_x(shard)) return kFail;                                   // G, b
         }
+        if (xg1_event) TRMF_HIP_CHECK(hipEventRecord(xg1_event, stream));
         if (p2p_use && (fused ? shard : uts)) p2p_fence(fused ? tsh_rank : ush);
         auto end_timed = [&]() -> int {
             if (!timed) return 0;
@@ -1851,7 +1928,7 @@ struct TrmfSessionImpl {
             snprintf(buf, sizeof buf, "1 rank; X-solve %s", generic ? "unfused; generic kernels for rank > 64 (Gram build, F-solve)"
                      : tile_TI <= 0 ? "unfused (AR tile + cached-Gram product per CG step)"
                      : persist_state == 1 ? "fused, one persistent kernel per solve" : persist_state == 0 ? "fused (not run yet)" : "fused, one launch per CG step");
-            return buf;
+            return persist_note.empty() ? std::string(buf) : std::string(buf) + " (" + persist_note + ")";
         }
         const bool fused = tile_TI > 0;
         std::string x;
@@ -1878,6 +1955,12 @@ struct TrmfSessionImpl {
 
     // ---- the ALS loop (trmf.cpp:647-693) --------------------------------------------------------------------
     int run(int iters) {
+        if (comm->world == 1 && snap_iter < 0 && period_W > 0 && iters > 0 && tile_TI > 0 && !persist_failed) {
+            // the persistent kernel is about to be used: the state to come back to if it times out (persist_recover)
+            const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);
+            FillStreamScope fill(stream);                 // (persist_usable() allocates the exchange tables on first use)
+            if (maxcg <= kCgHistCap && persist_usable(maxcg) && take_snapshot()) return kFail;
+        }
         for (int it = 0; it < iters; it++) {
             const int iter1 = ++iter;                       // 1-based like the reference
             DeviceIterLog *L = log.p + ((iter1 - 1) % kLogCap);
@@ -1900,8 +1983,12 @@ struct TrmfSessionImpl {
                 TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
             }
             TRMF_HIP_CHECK(hipEventRecord(ev.f1, stream));
+            if (!doX) TRMF_HIP_CHECK(hipEventRecord(ev.xg1, stream));
             if (doX) {
-                if (xsolve(device_log ? &L->x : nullptr, device_log ? &L->normF : nullptr)) return kFail;
+                xg1_event = ev.xg1;
+                const int xrc = xsolve(device_log ? &L->x : nullptr, device_log ? &L->normF : nullptr);
+                xg1_event = nullptr;
+                if (xrc) return kFail;
                 if (log_norms || verbose) log_norm(W.p, (size_t)T * KP, &L->normX);
                 if (!device_log)
                     TRMF_HIP_CHECK(hipMemcpyAsync(&L->x, xstate.p, sizeof(XState), hipMemcpyDeviceToDevice, stream));
@@ -1931,7 +2018,48 @@ struct TrmfSessionImpl {
         return 0;
     }
 
-    int sync() {
+    // ---- recovery when the persistent kernel's co-residency assumption breaks (one rank; VERDICT / ADVICE r4) -----------------
+    // The one-GPU X-solve is ONE kernel whose workgroups wait for each other; if something else holds compute units (a second
+    // process on the GPU) a poll runs into its bound, the kernel ends with XState::p2p_error set and every later persistent
+    // launch returns at once.  The iterates since then are void -- and a timeout in the last exchange can leave W half-updated
+    // -- so the session keeps a snapshot of (W, H, Theta, iteration counter) as of its last CHECKED synchronisation: sync()
+    // restores it, switches to the launch-per-step path (bit-identical iterates, no co-residency needed) for the rest of the
+    // session's life and repeats the iterations since the snapshot.  Cost: three device-to-device copies per sync()
+    // (18 MB at config 3, ~10 us), only while the persistent kernel is in use.
+    DevBuf<real> snapW, snapH, snapT;
+    int snap_iter = -1;
+    int take_snapshot() {
+        const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;
+        FillStreamScope fill(stream);
+        if (snapW.alloc(nw, false) || snapH.alloc(nh, false) || snapT.alloc(nt, false)) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(snapW.p, W.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(snapH.p, H.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(snapT.p, theta.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        snap_iter = iter;
+        return 0;
+    }
+    int persist_recover(const XState &hx) {
+        if (snap_iter < 0) { set_error("persistent CG kernel timed out and no snapshot exists"); return kFail; }
+        const int redo = iter - snap_iter;
+        if (verbose || getenv("TRMF_P2P_VERBOSE"))
+            fprintf(stderr, ">> persistent CG kernel: a poll ran into its bound (exchange %lld, tile %lld, %s missing; is another process using the GPU?): "
+                    "repeating %d iteration(s) with one launch per CG step\n", hx.p2p_diag[0], hx.p2p_diag[1], hx.p2p_diag[2] == 1 ? "records" : "halo rows", redo);
+        persist_state = -1; persist_failed = true;
+        persist_note = "the persistent kernel ran into a poll bound after iteration " + std::to_string(snap_iter) + ": one launch per CG step since";
+        const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;
+        TRMF_HIP_CHECK(hipMemsetAsync(&xstate.p->p2p_error, 0, sizeof(int), stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(W.p, snapW.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(H.p, snapH.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(theta.p, snapT.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        iter = snap_iter;
+        if (run(redo)) return kFail;
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        snapW.release(); snapH.release(); snapT.release(); snap_iter = -1;
+        return 0;
+    }
+
+    // recover = false: report a timed-out persistent kernel instead of repeating its iterations (session teardown)
+    int sync(bool recover = true) {
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
 #if defined(TRMF_PERSIST_PROF)
         if (persist_prof.p) {
@@ -1957,7 +2085,13 @@ struct TrmfSessionImpl {
             }
         }
 #endif
-        if (persist_state == 1 || (persist_shard_state == 1 && x_form == kXTsPersist)) {   // a bounded poll of the persistent CG kernel ran out (never observed; the GPU must not hang)
+        if (persist_state == 1 && comm->world == 1) {          // one rank: a timed-out solve is repeated on the launch-per-step path
+            XState hx;
+            TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));
+            if (hx.p2p_error && recover) return persist_recover(hx);
+            if (hx.p2p_error) { set_error("persistent CG kernel: an exchange between workgroups timed out"); return kFail; }
+            if (recover && snap_iter >= 0 && snap_iter != iter && take_snapshot()) return kFail;
+        } else if (persist_state == 1 || (persist_shard_state == 1 && x_form == kXTsPersist)) {   // several ranks: a bounded poll of the persistent CG kernel ran out (the GPU must not hang)
             XState hx;
             TRMF_HIP_CHECK(hipMemcpy(&hx, xstate.p, sizeof hx, hipMemcpyDeviceToHost));
             if (hx.p2p_error) { set_error("persistent CG kernel: an exchange between workgroups timed out (is another process using the GPU? TRMF_PERSIST=0 selects the launch-per-step path)"); return kFail; }
@@ -1971,7 +2105,7 @@ struct TrmfSessionImpl {
                          "peer %lld: expected epoch %lld, flag %lld", comm->rank, hx.p2p_diag[0] / 1000000, hx.p2p_diag[0] / 1000 % 1000 - 1,
                          hx.p2p_diag[0] % 1000, hx.p2p_diag[1], hx.p2p_diag[2]);
                 set_error(msg);
-                if (getenv("TRMF_P2P_DEBUG")) {       // what this rank derived its stop decisions from
+                if (test_env("TRMF_P2P_DEBUG")) {       // what this rank derived its stop decisions from
                     std::vector<double> hp((size_t)P_NSLOTS * xp.pstride);
                     TRMF_HIP_CHECK(hipMemcpy(hp.data(), pbase(), hp.size() * sizeof(double), hipMemcpyDeviceToHost));
                     fprintf(stderr, "[p2p debug] rank %d: %s\n  stop_it %d cg_iter %d rho %.17g %.17g %.17g gnorm %.17g cgtol %.9g\n", comm->rank, msg,
@@ -2002,7 +2136,8 @@ struct TrmfSessionImpl {
             o.f = hl.x.f; o.fnew = hl.x.fnew; o.actred = hl.x.actred; o.prered = hl.x.prered;
             o.gnorm = hl.x.gnorm; o.cg_rnorm = hl.x.cg_rnorm; o.cg_iter = hl.x.cg_iter; o.accepted = hl.x.accepted; o.delta = hl.x.delta;
             o.cg_rnorm_direct = hl.x.rho_direct >= 0 ? std::sqrt(hl.x.rho_direct) : -1.0;
-            o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = 0;
+            o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = o.ms_X_gram = 0;
+            (void)hipEventElapsedTime(&o.ms_X_gram, ev.f1, ev.xg1);
             (void)hipEventElapsedTime(&o.ms_F, ev.f0, ev.f1);
             (void)hipEventElapsedTime(&o.ms_F_kernel, ev.fk0, ev.fk1);
             (void)hipEventElapsedTime(&o.ms_X, ev.f1, ev.x1);

@@ -23,6 +23,9 @@ void set_error(const std::string &msg) {
 }
 
 static int g_device = 0;
+static std::mutex g_prof_mu;
+static TrmfTrainProfile g_last_profile;
+static bool g_have_profile = false;
 static std::shared_ptr<Comm> g_self = std::make_shared<SelfComm>();
 static std::shared_ptr<Comm> g_comm;
 // A session shares ownership of the communicator it was created under, so trmf_dist_finalize() before
@@ -174,24 +177,59 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
         pyW = &privW; pyH = &privH; pylag_val = &privLV;       // from here on the call works on the private model
     }
     DeviceGuard guard;                               // device of this library for the call, the caller's afterwards
+    // where the call's wall time goes (trmf_last_train_profile): set-up / compute / download / teardown
+    const double t0 = TrmfSessionImpl::now_s();
+    TrmfTrainProfile prof{};
+    const DevicePool::Stats ps0 = guard.ok ? DevicePool::current().stats() : DevicePool::Stats{};
     TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
                                       lambdaLag, period_W, period_H, period_Lag, missing, verbose);
-    if (s) s->log_norms = verbose > 0;       // the norm lines exist only under verbose (trmf.cpp:659-688)
-    if (!s) return;                                  // diagnostics already on stderr; outputs untouched
+    if (!s) {                                        // diagnostics already on stderr; outputs untouched
+        prof.failed = 1; prof.total_s = prof.setup_s = TrmfSessionImpl::now_s() - t0;
+        std::lock_guard<std::mutex> lk(g_prof_mu); g_last_profile = prof; g_have_profile = true;
+        return;
+    }
+    s->log_norms = verbose > 0;                      // the norm lines exist only under verbose (trmf.cpp:659-688)
+    const double t1 = TrmfSessionImpl::now_s();
     int rc = s->run(max_iter);
     if (rc == 0) rc = s->sync();
-    if (rc == 0) rc = s->download_padded(s->W, (real *)pyW->val, s->T);
-    if (rc == 0) rc = s->download_padded(s->H, (real *)pyH->val, s->n);
-    if (rc == 0 && s->nlag)
-        rc = hipMemcpy(pylag_val->val, s->theta.p, sizeof(real) * (size_t)s->nlag * s->k, hipMemcpyDeviceToHost) == hipSuccess ? 0 : kFail;
-    if (rc != 0) fprintf(stderr, "[ERR MSG]: device failure: %s\n", trmf_last_error());
+    const double t2 = TrmfSessionImpl::now_s();
+    // the factors come back through host staging and are committed together: a failure anywhere leaves W, H and lag_val as
+    // the caller passed them (the reference's contract for a failed call, trmf.cpp:632-634)
+    TrmfSessionImpl::StagedFactors staged;
+    if (rc == 0) rc = s->download_staged(staged);
+    if (rc == 0) staged.commit(pyW->val, pyH->val, pylag_val->val);
+    else fprintf(stderr, "[ERR MSG]: device failure, outputs untouched: %s\n", trmf_last_error());
+    staged.lease = std::unique_lock<std::mutex>();
+    const double t3 = TrmfSessionImpl::now_s();
+    prof.upload_s = s->t_upload_s; prof.bytes_h2d = s->bytes_uploaded;
+    prof.bytes_d2h = rc == 0 ? (double)(staged.bW + staged.bH + staged.bL) : 0.0;
     delete s;
+    const double t4 = TrmfSessionImpl::now_s();
+    const DevicePool::Stats ps1 = DevicePool::current().stats();
+    prof.total_s = t4 - t0; prof.setup_s = t1 - t0; prof.compute_s = t2 - t1; prof.download_s = t3 - t2; prof.teardown_s = t4 - t3;
+    prof.iters = max_iter; prof.device_mallocs = (int32_t)(ps1.hip_mallocs - ps0.hip_mallocs); prof.pool_reused = (int32_t)(ps1.reused - ps0.reused);
+    prof.failed = rc != 0;
+    std::lock_guard<std::mutex> lk(g_prof_mu); g_last_profile = prof; g_have_profile = true;
 }
 
 // ------------------------------------------------------------------------------------------------
 // Section 2
 // ------------------------------------------------------------------------------------------------
 int32_t trmf_sizeof_real(void) { return (int32_t)sizeof(real); }
+
+int32_t trmf_last_train_profile(TrmfTrainProfile *out) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_have_profile || !out) return kFail;
+    *out = g_last_profile;
+    return 0;
+}
+int32_t trmf_release_cached(void) {
+    DeviceGuard guard;
+    if (!guard.ok) return kFail;
+    DevicePool::current().trim();
+    StreamCache::drop_idle();
+    return 0;
+}
 
 int32_t trmf_device_count(void) {
     int cnt = 0;
@@ -294,7 +332,7 @@ int32_t trmf_session_describe(TrmfSession *s, char *buf, int32_t cap) {
 void trmf_session_destroy(TrmfSession *s) {
     if (!s) return;
     DeviceGuard guard;
-    (void)IMPL(s)->sync();
+    (void)IMPL(s)->sync(false);
     delete IMPL(s);
 }
 

@@ -20,7 +20,17 @@ class TrmfIterStats(ctypes.Structure):
                 ('gnorm', c_double), ('cg_rnorm', c_double),
                 ('cg_iter', c_int32), ('accepted', c_int32),
                 ('ms_F', c_float), ('ms_X', c_float), ('ms_LV', c_float), ('ms_F_kernel', c_float),
-                ('delta', c_double), ('cg_rnorm_direct', c_double)]
+                ('delta', c_double), ('cg_rnorm_direct', c_double), ('ms_X_gram', c_float), ('reserved_', c_float)]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class TrmfTrainProfile(ctypes.Structure):
+    """Split of the last c_trmf_train call of this process (include/trmf_abi.h)."""
+    _fields_ = [('total_s', c_double), ('setup_s', c_double), ('upload_s', c_double), ('compute_s', c_double),
+                ('download_s', c_double), ('teardown_s', c_double), ('bytes_h2d', c_double), ('bytes_d2h', c_double),
+                ('iters', c_int32), ('device_mallocs', c_int32), ('pool_reused', c_int32), ('failed', c_int32)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -40,6 +50,8 @@ def bind(lib):
     lib.trmf_set_device.argtypes = [c_int32]; lib.trmf_set_device.restype = c_int32
     lib.trmf_last_error.restype = c_char_p
     lib.trmf_device_free_bytes.restype = ctypes.c_int64
+    lib.trmf_last_train_profile.argtypes = [POINTER(TrmfTrainProfile)]; lib.trmf_last_train_profile.restype = c_int32
+    lib.trmf_release_cached.restype = c_int32
     lib.trmf_session_create.argtypes = [P, POINTER(c_uint32), c_uint32, P, P, P, c_double, c_double, c_double,
                                         c_int32, c_int32, c_int32, c_int32, c_int32]
     lib.trmf_session_create.restype = c_void_p
@@ -73,6 +85,12 @@ def bind(lib):
 
 def lib_for(dtype):
     return bind(get_clib().lib_for(dtype))
+
+
+def train_profile(dtype):
+    """Split of the last ``c_trmf_train`` call made through the library of ``dtype`` (None if there was none)."""
+    prof = TrmfTrainProfile()
+    return prof.as_dict() if lib_for(dtype).trmf_last_train_profile(byref(prof)) == 0 else None
 
 
 class Session(object):

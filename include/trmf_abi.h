@@ -74,7 +74,8 @@ typedef struct {
  * One ALS iteration = H(F)-solve, W(X)-solve, Theta-solve every period_Lag iterations
  * (trmf.cpp:647-693).  Outputs are written in place; Y and lag_set are never written.
  * Dimension/layout violations print the reference's "[ERR MSG]" lines on stderr and return
- * without touching the outputs (trmf.cpp:561-596,632-634).  warm_start == 0 reproduces the
+ * without touching the outputs (trmf.cpp:561-596,632-634).  So does every later failure (device
+ * error, out of memory): the three factors are staged on the host and committed together or not at all.  warm_start == 0 reproduces the
  * reference's behaviour: the reference rebuilds W, H and lag_val as
  * PRIVATE random matrices of matching shapes before its dimension check (trmf.cpp:547-558:
  * std::mt19937 seeded 0, uniform / normal draws in doubles cast to the element type), trains
@@ -114,6 +115,26 @@ TRMF_API void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t p
  * Section 2 -- build-owned additions (no reference counterpart)
  * ---------------------------------------------------------------------------------------------- */
 
+/* Where the wall time of the LAST completed c_trmf_train call of this process went (round 5).  The reference's entry wraps
+ * the caller's buffers zero-copy (trmf.cpp:696-725); this one has to put the problem into HBM and bring the factors back:
+ *   setup_s     validation, device memory (a process-level pool: device_mallocs counts the hipMalloc calls of THIS call, 0
+ *               once the pool holds the shape), the caller's arrays through a pinned ring (upload_s of it: the time the host
+ *               spent reading them; bytes_h2d), padding / narrowing on the device, events, the set-up's one synchronisation
+ *   compute_s   max_iter ALS iterations enqueued + the final synchronisation
+ *   download_s  factors -> pinned staging -> the caller's arrays, committed only when ALL of them have arrived
+ *   teardown_s  releasing the session (buffers back to the pool, no hipFree)
+ * total_s is measured around the whole call; the four parts add up to it. */
+typedef struct {
+    double total_s, setup_s, upload_s, compute_s, download_s, teardown_s;
+    double bytes_h2d, bytes_d2h;
+    int32_t iters, device_mallocs, pool_reused, failed;
+} TrmfTrainProfile;
+/* 0 and *out filled when a c_trmf_train call has completed in this process (and library), -1 otherwise. */
+TRMF_API int32_t trmf_last_train_profile(TrmfTrainProfile *out);
+/* Give back what the library keeps between calls on the selected device: pooled device memory (when no session is alive),
+ * idle streams.  TRMF_POOL_MAX_MB (default 8192, 0 = keep nothing) bounds the pool.  Returns 0. */
+TRMF_API int32_t trmf_release_cached(void);
+
 /* sizeof(element type) of this library: 4 or 8. */
 TRMF_API int32_t trmf_sizeof_real(void);
 /* Number of visible HIP devices (0 if none / runtime unusable). */
@@ -137,6 +158,9 @@ typedef struct {
     double delta;                          /* trust-region bound of the TRON line (rf_tron.h:195-219) */
     double cg_rnorm_direct;                /* |-g - H s| of the step evaluated directly; cg_rnorm is the CG's recurrence
                                               (-1 where not evaluated: only the one-GPU persistent kernel does)   */
+    float ms_X_gram;                       /* HIP-event time from the start of the X phase to the end of its Gram build
+                                              (gram_x_kernel + gathers); ms_X - ms_X_gram is the CG solve              */
+    float reserved_;
 } TrmfIterStats;
 
 typedef struct TrmfSession TrmfSession;

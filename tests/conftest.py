@@ -9,6 +9,11 @@ for p in (os.path.join(ROOT, 'exp-trmf-nips16_amd'), os.path.join(ROOT, 'oracle'
         sys.path.insert(0, p)
 
 
+# The library reads its test-only knobs (forced forms, forced failures, ablations: TRMF_GRAMX, TRMF_P2P_FAIL, TRMF_NO_HV_TILE, ...)
+# only when TRMF_TEST is set; worker processes of the multi-rank tests inherit it.
+os.environ.setdefault('TRMF_TEST', '1')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 

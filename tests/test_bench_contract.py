@@ -27,6 +27,22 @@ def test_traffic_profile_belongs_to_the_current_kernel_sources():
         assert os.path.exists(os.path.join(ROOT, tj['source']))
 
 
+def test_x_phase_byte_models():
+    """roofline_x of the bench line: B_G and B_cg of SURVEY.md 8(d) "X-side figures" at the headline configuration."""
+    import numpy as np
+    import bench
+    from trmf import synth
+    cfg = synth.CONFIGS['c3']
+    nnz, T, k, s = 9950287, 10000, 40, 4
+    b_g, b_cg = bench.x_byte_models(cfg, nnz, s)
+    assert b_g == nnz * (4 + s + k * s) + (T + 1) * 8 + T * (k * k + k) * s == 1737328224
+    assert b_cg == T * k * k * s + 6 * T * k * s == 73600000
+    r = bench.roofline_x(cfg, nnz, np.dtype(np.float32), True, 1, 0.2645, 0.529, 16.0, '1 rank')
+    assert abs(r['gram']['achieved'] - b_g / 0.2645e-3 / 1e9) < 1e-6 and abs(r['gram']['frac'] - r['gram']['achieved'] / 8000.0) < 1e-12
+    assert r['cg']['operator_passes_per_solve'] == 18.0 and abs(r['cg']['us_per_pass'] - 1e3 * (0.529 - 0.2645) / 18.0) < 1e-9
+    assert bench.roofline_x(cfg, nnz, np.dtype(np.float32), True, 2, 0.2, 0.5, 16.0, '') is None       # one rank only
+
+
 def test_cpu_baseline_worker_protocol():
     """The child process of bench.py's cpu_baseline: full-iteration time and the F / X / Theta split, one JSON line."""
     res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--cpu-baseline-worker', 'port', '--config', 'tiny',

@@ -200,22 +200,6 @@ def test_fp32_parity_near_convergence_40_iterations():
     assert relfro(model.W, W) < 2e-3 and relfro(model.H, H) < 2e-3
 
 
-@pytest.mark.parametrize('form', ['wave'])
-def test_alternative_fsolve_forms_match(form, monkeypatch):
-    """fp32 F-solve through the other kernel behind TRMF_FSOLVE (one wavefront per row): same systems, same
-    answers as the default quad form."""
-    p = synth.sparse_problem(n=900, T=400, k=40, nlag=4, density=0.08, dtype=np.float32, seed=3)
-    m0 = synth.initial_model(p['Y'], p['lag_set'], 40, seed=3)
-    big = 10 ** 6
-    ref = run_product(p['Y'], p['lag_set'], m0.W, m0.H, m0.lag_val, synth.HYPER, 1, periods=(big, 1, big))
-    monkeypatch.setenv('TRMF_FSOLVE', form)
-    alt = run_product(p['Y'], p['lag_set'], m0.W, m0.H, m0.lag_val, synth.HYPER, 1, periods=(big, 1, big))
-    assert relmax(alt.H, ref.H) < 2e-4
-    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
-    O.train_port(p['Y'], p['lag_set'], W, H, Th, synth.HYPER, max_iter=1, periods=(big, 1, big))
-    assert relmax(alt.H, H) < 2e-4
-
-
 def test_empty_rows_and_columns_are_left_untouched():
     rng = np.random.RandomState(5)
     Y = smat.random(120, 90, density=0.1, random_state=rng, format='lil', dtype=np.float64)
