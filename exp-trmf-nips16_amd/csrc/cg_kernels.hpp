@@ -102,6 +102,7 @@ __device__ __forceinline__ bool cg_stopped(real rho, real cgtol) {           // 
 }
 
 // ---- single-block reduction of a per-row array into a scalar ----------------------------------------
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restrict__ src, int n,
                                                           double *__restrict__ dst) {
     __shared__ double smem[256];
@@ -110,8 +111,10 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const double *__restri
     v = block_allsum(v, smem);
     if (threadIdx.x == 0) *dst = v;
 }
+#endif
 
 // ---- ||v||_F^2 partials (verbose log lines trmf.cpp:661,672,687) -----------------------------------
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void sumsq_partial_kernel(const real *__restrict__ v, size_t n,
                                                             double *__restrict__ P) {
     __shared__ double smem[256];
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const real *__restri
     acc = block_allsum(acc, smem);
     if (threadIdx.x == 0) P[blockIdx.x] = acc;
 }
+#endif
 
 // ---- AR + ridge part of the operator, tiled over (time x column group) in LDS ------------------------------
 // base = lambdaI*v + lambdaAR*AR'(AR(v)) for the unfused path (lag sets whose reach does not fit hv_tile_kernel's
@@ -719,6 +723,7 @@ __device__ __forceinline__ real *edge_base(double *msg, const TileShard &sh, int
 }
 // The neighbours' edge rows -> their natural rows of the local vectors (rows [row_b - midx, row_b) from the LAST rows of
 // rank - 1, rows [row_e, row_e + midx) from the FIRST rows of rank + 1).
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void halo_unpack_kernel(const double *__restrict__ msg, TileShard sh,
                                                           int edgeN /* midx * KP */, int KP, int nvec,
                                                           real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2) {
@@ -734,6 +739,7 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(const double *__restri
             for (int e = blockIdx.x * 256 + threadIdx.x; e < edgeN; e += gridDim.x * 256) dst[v][row0 + e] = src[(size_t)v * edgeN + e];
     }
 }
+#endif
 
 // Workgroup b -> tile, such that the workgroups an XCD receives (b % 8 == x on gfx950's round-robin dispatch) own one
 // contiguous range of tiles.  A bijection on [0, n) for every n; changes only which workgroup does which tile.
@@ -746,6 +752,7 @@ __device__ __forceinline__ int xcd_contiguous_tile(int b, int n) {
 
 // This rank's first / last midx rows of up to three vectors -> its slot of an edge message (the time-sharded UNFUSED CG: its
 // kernels do not export edges themselves; hv_tile_kernel and cg_close_kernel do).
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void edge_pack_kernel(double *__restrict__ msg, TileShard sh, int edgeN, int KP, int nvec,
                                                         const real *__restrict__ v0, const real *__restrict__ v1,
                                                         const real *__restrict__ v2) {
@@ -758,6 +765,7 @@ __global__ __launch_bounds__(256) void edge_pack_kernel(double *__restrict__ msg
                 edges[((size_t)side * kEdgeVecs + v) * edgeN + e] = src[v][row0 + e];
     }
 }
+#endif
 
 // ---- peer-to-peer form of the exchange (TRMF_CG=p2p) ---------------------------------------------------------------------
 // The all-gather of a message costs a collective launch (tens of microseconds) per CG step -- more than the step itself
@@ -778,6 +786,7 @@ struct PeerTable {                              // lives in device memory (index
 constexpr int kFlagStride = 8;                  // 64 bytes between the flags of different source ranks
 constexpr long long kP2pTimeoutTicks = 1000000000;  // 10 s of the 100 MHz wall clock
 constexpr long long kP2pTrialTicks = 20000000;      // 200 ms: the trial exchange of the set-up (a failure there only means "use the communicator")
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restrict__ pt, int mi, unsigned long long epoch, XState *__restrict__ st, int it,
                                                         TileShard sh, int edgeN, int KP, int nvec,
                                                         real *__restrict__ v0, real *__restrict__ v1, real *__restrict__ v2,
@@ -816,6 +825,7 @@ __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restr
             for (int e = tid; e < edgeN; e += 256) dst[v][row0 + e] = __builtin_nontemporal_load(src + (size_t)v * edgeN + e);
     }
 }
+#endif
 
 // Peer-to-peer exchange of the time-sharded UNFUSED CG: its kernels keep their partial sums in arrays and do not export edges,
 // so one small kernel pushes what the peers need after each operator application -- this rank's entries of up to four
@@ -824,6 +834,7 @@ __global__ __launch_bounds__(256) void xchg_sync_kernel(const PeerTable *__restr
 // the previous exchange's edges when this rank, one operator application further, pushes the next) -- and xchg_sync_kernel
 // follows (flags, halo rows).
 struct PushList { int n; int slot[4], begin[4], count[4]; };
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void uts_push_kernel(const PeerTable *__restrict__ pt, int mi, const XState *__restrict__ st, int it,
                                                        TileShard sh, int pstride, PushList pl, int edgeN, int KP, int nvec,
                                                        const real *__restrict__ v0, const real *__restrict__ v1, const real *__restrict__ v2) {
@@ -849,7 +860,18 @@ __global__ __launch_bounds__(256) void uts_push_kernel(const PeerTable *__restri
     }
     __threadfence_system();
 }
+#endif
 
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int MODE, int KQ, bool SHARD>
+__global__ void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
+                                                         int it, int last,
+                                                         const uint32_t *__restrict__ lag_set,
+                                                         const real *__restrict__ theta,
+                                                         const real *__restrict__ G,
+                                                         const double *__restrict__ rec_in, double *__restrict__ rec_out,
+                                                         const PeerTable *__restrict__ pt, int mi, int TI);
+#else
 template <int MODE, int KQ, bool SHARD>
 __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,
@@ -1285,8 +1307,10 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     if (threadIdx.x == 0) put_record(0, ar2, vv, dot, lq, GRAD);     // [2]: <g,g> of the gradient launch, <v,Hv> of the plain one
     if (p2p) __threadfence_system();
 }
+#endif
 
 // ---- CG initialisation: f, |g|, tolerances; s = 0, r = -g, d = r  (rf_tron.h:154-169, 424-439) ----
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restrict__ st,
                                                       double *__restrict__ Pbase, int np_base,
                                                       int np_dot, const real *__restrict__ g,
@@ -1322,8 +1346,10 @@ __global__ __launch_bounds__(256) void cg_init_kernel(XParams p, XState *__restr
         s[e] = 0; r[e] = -gv; d[e] = -gv;
     }
 }
+#endif
 
 // ---- w_new = w + s ; partials <g,s>, <s,r>  (rf_tron.h:183-190) --------------------------------------
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__restrict__ st,
                                                    const real *__restrict__ w,
                                                    const real *__restrict__ s,
@@ -1349,6 +1375,7 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__re
         Pbase[P_SS * (size_t)p.pstride + slot0 + blockIdx.x] = ss;
     }
 }
+#endif
 
 // ---- acceptance test and commit (rf_tron.h:191-229) -------------------------------------------------
 // The X sub-problem is exactly quadratic, so f(w+s) - f(w) = g.s + 1/2 s.Hs.  The reference evaluates
@@ -1356,6 +1383,7 @@ __global__ __launch_bounds__(256) void wnew_kernel(XParams p, const XState *__re
 // extra Hessian-vector product H s (cached Grams, no gather) gives the same reduction without the
 // cancellation of subtracting two large objective values.  Every block derives the same decision;
 // block 0 records the TRON line values.
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restrict__ st,
                                                      const double *__restrict__ Pbase, int np,
                                                      int np_dot, const double *__restrict__ Prr_final,
@@ -1404,6 +1432,7 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
         }
     }
 }
+#endif
 
 // ---- closing the CG of the fused path (rf_tron.h:460-461, 183-190) ---------------------------------------------------
 // The CG launches stop at the top of iteration `stop_it` without touching anything.  This kernel closes iteration
@@ -1478,6 +1507,7 @@ __global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *
 // ---- acceptance test and commit of the fused path: sums of the per-tile records -----------------------------------
 // <g,s>, <s,r>, <s,s> (cg_close_kernel) and <s,Hs> (plain launch) sit in the same records; with several ranks a rank
 // commits its own timestamps [row_b, row_e) (the rows of W are all-gathered next).
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msgP,
                                                           TileShard sh, int sharded, const real *__restrict__ w_new,
                                                           real *__restrict__ w, XState *__restrict__ log_x,
@@ -1524,5 +1554,6 @@ __global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__r
         }
     }
 }
+#endif
 
 }  // namespace trmf

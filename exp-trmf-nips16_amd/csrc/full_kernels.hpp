@@ -16,6 +16,15 @@ namespace trmf {
 
 // ---- out[row][:] = sum_j val * X[idx][:]  (sparse Y times a factor): one wavefront per row ----------
 // `out` is rows x KP in LOGICAL column order (it is a right-hand side, not a factor).
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT>
+__global__ void spmm_rows_kernel(const uint32_t *__restrict__ ptr,
+                                                        const uint32_t *__restrict__ idx,
+                                                        const real *__restrict__ val,
+                                                        const real *__restrict__ X,
+                                                        real *__restrict__ out, uint32_t row_begin,
+                                                        uint32_t row_end, uint32_t zero_row);
+#else
 template <int NT>
 __global__ __launch_bounds__(256) void spmm_rows_kernel(const uint32_t *__restrict__ ptr,
                                                         const uint32_t *__restrict__ idx,
@@ -46,6 +55,7 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const uint32_t *__restri
         if (g == 0) out[(size_t)row * KP + kTile * q + c] = v;
     }
 }
+#endif
 
 // ---- C[m][:] = sum_j A[j][m] * B[j][:]  (dense A: K x M row-major; B: factor, K x KP interleaved) -----
 // The dense contraction of the full-observation path (gmat_x_dmat / dmat_x_dmat -> BLAS gemm in the reference,
@@ -57,6 +67,12 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const uint32_t *__restri
 // to fill the chip when C has only a few hundred rows); the chunk partials are summed in fixed order by
 // dense_tn_reduce_kernel.  Products and sums inside a chunk are val_type fused multiply-adds in K order
 // (like a gemm micro-kernel); across chunks the sum is fp64.
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT>
+__global__ void dense_tn_mfma_kernel(const real *__restrict__ A, int K, int M,
+                                                            const real *__restrict__ B,
+                                                            double *__restrict__ part);
+#else
 template <int NT>
 __global__ __launch_bounds__(256) void dense_tn_mfma_kernel(const real *__restrict__ A, int K, int M,
                                                             const real *__restrict__ B,
@@ -97,9 +113,11 @@ __global__ __launch_bounds__(256) void dense_tn_mfma_kernel(const real *__restri
             if (m < M) part[((size_t)ch * M + m) * KP + NT * c + q] = (double)acc[q][r];
         }
 }
+#endif
 // out (M x KP, LOGICAL columns) = sum over chunks; positions of B's interleaved layout mapped back.
 // One wavefront per output element: lanes stride over the chunks, then a fixed-order butterfly -- the
 // chunk count goes up to ~1000 for tall-skinny products (few output rows, long contraction).
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void dense_tn_reduce_kernel(const double *__restrict__ part, int nchunk,
                                                               int M, int KP, int NT, int k,
                                                               real *__restrict__ out) {
@@ -113,8 +131,10 @@ __global__ __launch_bounds__(256) void dense_tn_reduce_kernel(const double *__re
     const int t = collog(tp, NT);
     if (lane == 0) out[(size_t)m * KP + t] = (t < k) ? (real)acc : real(0);
 }
+#endif
 
 // few chunks (many output rows, short contraction): one thread per output element, same fixed chunk order
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void dense_tn_reduce_flat_kernel(const double *__restrict__ part, int nchunk,
                                                                    int M, int KP, int NT, int k,
                                                                    real *__restrict__ out) {
@@ -126,12 +146,18 @@ __global__ __launch_bounds__(256) void dense_tn_reduce_flat_kernel(const double 
     for (int ch = 0; ch < nchunk; ch++) acc += part[((size_t)ch * M + m) * KP + tp];
     out[e] = (t < k) ? (real)acc : real(0);
 }
+#endif
 
 // ---- small Gram: GS (k x k, logical) = A^T A (+ lambda I) over the rows of a factor ------------------
 // A SYRK over contiguous factor rows on the matrix pipe: every wavefront takes a contiguous chunk of rows, four
 // rows per MFMA K-slice, operands loaded in fragment layout (the lane's NT adjacent values of a row), upper
 // tiles only; its k x k partial (both triangles, fp64) goes to slot blockIdx.x * 4 + wave and the slots are
 // reduced in fixed order by small_gram_reduce_kernel.
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT>
+__global__ void small_gram_mfma_kernel(const real *__restrict__ A, int rows, int k,
+                                                              double *__restrict__ part);
+#else
 template <int NT>
 __global__ __launch_bounds__(256) void small_gram_mfma_kernel(const real *__restrict__ A, int rows, int k,
                                                               double *__restrict__ part) {
@@ -179,7 +205,9 @@ __global__ __launch_bounds__(256) void small_gram_mfma_kernel(const real *__rest
                 }
             }
 }
+#endif
 // one wavefront per entry: lanes stride over the workgroup partials, fixed-order butterfly
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void small_gram_reduce_kernel(const double *__restrict__ part, int nblk,
                                                                 int k, real lambda, real *__restrict__ GS) {
     const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -191,6 +219,7 @@ __global__ __launch_bounds__(256) void small_gram_reduce_kernel(const double *__
     if (e / k == e % k) v += lambda;                                         // trmf.cpp:322-324
     if (lane == 0) GS[e] = v;
 }
+#endif
 
 // ---- shared-matrix solve: H[i][:] = GS^-1 b_i for every row (posv with n right-hand sides, trmf.cpp:333) ----
 // chol_shared_kernel: ONE workgroup factorises the k x k matrix in LDS (upper Cholesky in val_type, as posv 'U')
@@ -199,6 +228,7 @@ __global__ __launch_bounds__(256) void small_gram_reduce_kernel(const double *__
 // every remaining lane has had its U(.,.) * z_q term removed -- so a row costs 2k broadcast + FMA steps on 64 lanes
 // instead of k^2 dependent LDS round trips on one thread.  Forward: the same subtractions in the same order as the
 // row-oriented loop; backward: a row's terms are subtracted in descending instead of ascending order (last bit).
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void chol_shared_kernel(const real *__restrict__ GS, real *__restrict__ Uout, int k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ss_raw[];
     real *U = reinterpret_cast<real *>(ss_raw);          // k x k
@@ -218,12 +248,17 @@ __global__ __launch_bounds__(256) void chol_shared_kernel(const real *__restrict
     }
     for (int e = threadIdx.x; e < k * k; e += 256) Uout[e] = U[e];
 }
+#endif
 // chol_wave_kernel: the same factorisation by ONE wavefront without LDS or barriers.  Lane c keeps column c of the
 // matrix in registers (KMAX values; rows and columns >= k padded with the identity, so no step needs a guard); step
 // j scales row j and subtracts u_js * u_jc from every later row s, u_js arriving as a scalar through v_readlane
 // with a compile-time lane -- the loops are fully unrolled.  Same operations per element as chol_shared_kernel
 // (sqrt, divide, one fused multiply-subtract), ~4x faster at k = 60 (70 -> 18 us): the workgroup version is a chain
 // of 3 k barriers and LDS round trips.  Writes U (upper part, zeros below).
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT>
+__global__ void chol_wave_kernel(const real *__restrict__ GS, real *__restrict__ Uout, int k);
+#else
 template <int NT>
 __global__ __launch_bounds__(64) void chol_wave_kernel(const real *__restrict__ GS, real *__restrict__ Uout, int k) {
     constexpr int KMAX = kTile * NT;
@@ -249,7 +284,9 @@ __global__ __launch_bounds__(64) void chol_wave_kernel(const real *__restrict__ 
             if (s < k) Uout[(size_t)s * k + c] = s <= c ? a[s] : real(0);
     }
 }
+#endif
 // dynamic LDS = k * k * sizeof(real); k <= 64: lane p holds unknown p
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
 __global__ __launch_bounds__(256) void solve_rows_kernel(const real *__restrict__ Ug, const real *__restrict__ Brows,
                                                          real *__restrict__ out, int rows, int k, int KP, int NT) {
     extern __shared__ __attribute__((aligned(16))) unsigned char ss_raw[];
@@ -275,6 +312,7 @@ __global__ __launch_bounds__(256) void solve_rows_kernel(const real *__restrict_
         if (lane < k) out[(size_t)i * KP + colpos(lane, NT)] = x;
     }
 }
+#endif
 
 // ---- unfused CG with ONE Gram for every timestamp: out = base + V G (- B), on the matrix pipe -------------------
 // apply_kernel (cg_kernels.hpp) spends two LDS reads per multiply-add when the Gram is shared; here the product of a
@@ -294,6 +332,15 @@ __host__ __device__ constexpr int apply_tile_pitch(int KP) { return KP + 4; }   
 __host__ __device__ constexpr size_t apply_shared_lds_bytes(int KP) {
     return (size_t)KP * apply_gram_pitch(KP) * sizeof(double) + (size_t)4 * kApplyTile * apply_tile_pitch(KP) * sizeof(real);
 }
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT>
+__global__ void apply_shared_mfma_kernel(XParams p, const XState *__restrict__ st, int cg_it,
+                                                                const real *__restrict__ v, const real *__restrict__ rvec,
+                                                                const real *__restrict__ base, const real *__restrict__ G,
+                                                                const real *__restrict__ Bv, int minus_b,
+                                                                real *__restrict__ out, int dot_mode,
+                                                                double *__restrict__ Pdot, int row0, int nrows, int slot0);
+#else
 template <int NT>
 __global__ __launch_bounds__(256) void apply_shared_mfma_kernel(XParams p, const XState *__restrict__ st, int cg_it,
                                                                 const real *__restrict__ v, const real *__restrict__ rvec,
@@ -394,5 +441,6 @@ __global__ __launch_bounds__(256) void apply_shared_mfma_kernel(XParams p, const
     lq = block_allsum(lq, smem);
     if (threadIdx.x == 0) { Pdot[slot0 + blockIdx.x] = dot; Pdot[(P_LQ - P_DOT) * (size_t)p.pstride + slot0 + blockIdx.x] = lq; }
 }
+#endif
 
 }  // namespace trmf

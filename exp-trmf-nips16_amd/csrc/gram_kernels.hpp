@@ -391,6 +391,16 @@ __device__ __forceinline__ void fmac4_row_bcast(double &acc, const Quad<double> 
 #define TRMF_TRAIL_MFMA 1      // measured at config 5: 12.6-12.8 ms with the MFMA trailing update, 13.0 ms with the DPP-fused FMAs (7b)
 #endif
 
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT, int KMAX, bool TRAIL_MFMA = (TRMF_TRAIL_MFMA != 0)>
+__global__ void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
+                                                                          const uint32_t *__restrict__ idx,
+                                                                          const real *__restrict__ val,
+                                                                          const real *__restrict__ X,
+                                                                          real *__restrict__ F, uint32_t row_begin,
+                                                                          uint32_t row_end, int k, real lambda,
+                                                                          uint32_t zero_row);
+#else
 template <int NT, int KMAX, bool TRAIL_MFMA = (TRMF_TRAIL_MFMA != 0)>
 __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
                                                                           const uint32_t *__restrict__ idx,
@@ -580,6 +590,7 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
     });
     if (lane < k) F[(size_t)row * KP + colpos(lane, NT)] = y * dinv;
 }
+#endif
 #endif  // !TRMF_F32
 
 #if defined(TRMF_F32)
@@ -729,6 +740,16 @@ struct QuadStream {
 // <4,64> instantiations spilled 296 / 460 bytes per lane; they are built for two wavefronts per SIMD instead.
 // (profiles/r04_fsolve_k64_fp32.txt has the comparison).
 constexpr int quad_waves(int NT) { return NT >= 4 ? 2 : TRMF_QUAD_WAVES; }
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT, int KMAX, int ABL = 0>
+__global__ void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
+                                                          const uint32_t *__restrict__ idx,
+                                                          const float *__restrict__ val,
+                                                          const float *__restrict__ X,
+                                                          float *__restrict__ F, uint32_t row_begin,
+                                                          uint32_t row_end, int k, float lambda,
+                                                          uint32_t zero_row);
+#else
 template <int NT, int KMAX, int ABL = 0>
 __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,
@@ -832,6 +853,7 @@ __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const 
         *reinterpret_cast<RealVec<NT> *>(F + (size_t)(row0 + grp) * KP + NT * c) = o;
     }
 }
+#endif
 
 #endif  // TRMF_F32
 
@@ -842,6 +864,16 @@ __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const 
 // only, row s at s k - s (s - 1) / 2, `gs` elements per timestamp.  No LDS, no workgroup barrier: a timestamp has ~nnz/T entries (1000 at
 // config 3), so one wavefront amortises the ring's two-iteration lead 60x instead of 15x, and the four
 // wavefronts of a workgroup never wait for each other.
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT, bool RHS_PAD, bool PACKED>
+__global__ void gram_x_kernel(const uint32_t *__restrict__ ptr,
+                                                     const uint32_t *__restrict__ idx,
+                                                     const real *__restrict__ val,
+                                                     const real *__restrict__ Hf,
+                                                     real *__restrict__ G, real *__restrict__ Bv,
+                                                     uint32_t row_begin, uint32_t row_end, int k,
+                                                     uint32_t zero_row, size_t gs);
+#else
 template <int NT, bool RHS_PAD, bool PACKED>
 __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ idx,
@@ -909,8 +941,20 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
                 }
             }
 }
+#endif
 
 // ---- loss only (f(w_new) of the TRON acceptance test, rf_tron.h:191) ------------------------------
+#if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
+template <int NT>
+__global__ void loss_kernel(const uint32_t *__restrict__ ptr,
+                                                   const uint32_t *__restrict__ idx,
+                                                   const real *__restrict__ val,
+                                                   const real *__restrict__ Hf,
+                                                   const real *__restrict__ W,
+                                                   double *__restrict__ lossrow,
+                                                   uint32_t row_begin, uint32_t row_end,
+                                                   uint32_t zero_row);
+#else
 template <int NT>
 __global__ __launch_bounds__(256) void loss_kernel(const uint32_t *__restrict__ ptr,
                                                    const uint32_t *__restrict__ idx,
@@ -945,5 +989,6 @@ __global__ __launch_bounds__(256) void loss_kernel(const uint32_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) lossrow[row] = (Sl[0] + Sl[1]) + (Sl[2] + Sl[3]);
 }
+#endif
 
 }  // namespace trmf

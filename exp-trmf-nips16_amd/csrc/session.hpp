@@ -23,14 +23,12 @@
 #include <vector>
 
 #include "../../include/trmf_abi.h"
-#include "cg_kernels.hpp"
-#include "cg_persist.hpp"
+#include "kernel_units.hpp"      // cg_kernels.hpp, cg_persist.hpp, gram_kernels.hpp + which unit compiles which instantiation
 #include "comm.hpp"
 #include "full_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "common.hpp"
 #include "device_pool.hpp"
-#include "gram_kernels.hpp"
 #include "resident_kernels.hpp"
 #include "theta_kernels.hpp"
 
