@@ -15,6 +15,8 @@
 //                 and unpack kernel as RcclComm, so two ranks on one GPU exercise them.
 #pragma once
 
+#include <atomic>
+
 #include <dlfcn.h>
 
 #include <algorithm>
@@ -29,6 +31,9 @@ namespace trmf {
 
 struct Comm {
     int rank = 0, world = 1;
+    // distinguishes communicators in the process-level cache of measure-once decisions (session.hpp): a new communicator
+    // (other connections, maybe other devices) never inherits what was measured under an old one
+    const uint64_t id = [] { static std::atomic<uint64_t> next{1}; return next.fetch_add(1); }();
     bool call_when_single = false;   // issue the (degenerate) gather even for world == 1
     virtual ~Comm() {}
     // Gather in place: rank r owns bytes [off[r], off[r+1]) of dbuf (device memory).

@@ -1,0 +1,303 @@
+// session_state.hpp -- the HBM-resident state of a TRMF session: every data member, in one place (round 5: session.hpp was a
+// 2000-line monolith).  The layers above add behaviour only:
+//   SessionState  ->  SessionTransport (session_transport.hpp: communicator gathers, peer-to-peer arenas, exchanges)
+//                 ->  SessionFPhase    (session_fphase.hpp: the F-solve and its sharding / overlap)
+//                 ->  SessionXPhase    (session_xphase.hpp: X-side Gram build, the forms of the CG, Theta)
+//                 ->  TrmfSessionImpl  (session.hpp: set-up, growth, measure-once decisions, the ALS loop, recovery, statistics)
+//
+// HBM layout (all resident for the lifetime of a session):
+//   Yc_*   CSC of Y viewed as CSR over items   (F-solve rows):  ptr u32[n+1], idx u32[nnz], val[nnz]
+//   Yr_*   CSR of Y over timestamps            (X-side rows):   ptr u32[T+1], idx u32[nnz], val[nnz]
+//   W      T x KP, H  n x KP   (KP = k rounded up to 16, zero padded, row-major, columns interleaved)
+//   theta  |L| x k column-major (as the ABI delivers it)
+//   G      T x k x k   cached per-timestamp Gram,  Bv  T x KP rhs,  lossrow  T doubles
+//   CG     g, s, r/r1, d0/d1, Hd/Hd1, w_new, arbase: T x KP each; partial-sum arrays
+#pragma once
+
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "../../include/trmf_abi.h"
+#include "comm.hpp"
+#include "dev_buf.hpp"
+#include "full_kernels.hpp"
+#include "generic_kernels.hpp"
+#include "resident_kernels.hpp"
+#include "theta_kernels.hpp"
+
+namespace trmf {
+
+std::shared_ptr<Comm> active_comm();   // trmf_abi.hip
+
+struct SessionState {
+    // problem
+    int T = 0, n = 0, k = 0, KP = 0, NT = 0, KMAX = 0, nlag = 0, midx = 0;
+    uint64_t nnz = 0;
+    double lambdaI = 0, lambdaAR = 0, lambdaLag = 0;
+    int period_W = 1, period_H = 1, period_Lag = 2, verbose = 0;
+    bool log_norms = true;       // ||.||^2 records of the iteration log (the reference: only under verbose)
+    int max_cg_iter = 20;        // 10 * 2, trmf.h:90-93 folded by trmf.cpp:603-606
+    double eps_cg = 0.1;
+    int iter = 0;                // ALS iterations done so far
+    // distribution
+    std::shared_ptr<Comm> comm;      // shared with the library: outlives trmf_dist_finalize() while the session lives
+    std::vector<uint64_t> fbounds, xbounds;   // row partitions of items / timestamps
+    // device
+    hipStream_t stream = nullptr;
+    DevBuf<uint32_t> Yc_ptr, Yc_idx, Yr_ptr, Yr_idx, lag_set, lag_steps;   // lag_steps: ar_lag_steps() of the lag set
+    int nsteps = 0;
+    DevBuf<real> Yc_val, Yr_val, W, H, theta, G, Bv, g, s, r, r1, d0, d1, Hd, Hd1, w_new;
+    DevBuf<double> lossrow, partials, theta_part;
+    // full-observation path (missing == 0)
+    bool full = false, dense = false;
+    DevBuf<real> Yd_tn, Yd_nt;                // dense Y as T x n and as n x T (both row-major)
+    DevBuf<real> Bf, GSf, GSx, Uf;            // F-side right-hand sides (n x KP), shared Grams (k x k), Cholesky factor of GSf
+    DevBuf<double> gemm_part, sgram_part;
+    double trYTY = 0;
+    static constexpr int kGemmChunks = 32, kSmallGramBlocks = 256;
+    DevBuf<XState> xstate;
+    DevBuf<DeviceIterLog> log;
+    static constexpr int kLogCap = 4096;
+    std::vector<PhaseEvents> events;
+    static constexpr int kEventRing = 64;
+    int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
+    bool generic = false;                     // 64 < k <= 256: generic_kernels.hpp for the Grams / the F-solve, unfused CG
+    DevBuf<real> gen_scratch, theta_scratch;  // k x k systems of the generic F-solve; |L| x |L| systems of long lag sets
+    bool gpacked = false;                     // unfused path: G holds upper triangles (packed_gram_elems(k) per timestamp), apply_kernel<true>
+    int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), tiles of the problem
+    // fused path: per-tile records of each launch (cg_kernels.hpp "per-tile partial records") in three message buffers:
+    // CG launches of even / odd iteration, gradient + plain launch.  tsh: the one-rank view (one slot, every tile);
+    // tsh_rank: this rank's block of tiles when the CG is sharded over time (ts_possible).
+    DevBuf<double> xmsg_own[3];               // backing store of the messages unless they live in the peer-to-peer arena
+    double *xm[3] = {nullptr, nullptr, nullptr};
+    TileShard tsh{}, tsh_rank{};
+    // peer-to-peer exchange (TRMF_CG=p2p; cg_kernels.hpp "peer-to-peer form of the exchange"): messages + flag words of
+    // this rank in one IPC-exported arena, the peers' arenas opened, the pointer table in device memory
+    struct P2p {
+        bool on = false;                      // arena allocated, exported, mapped by every peer, and the trial exchange passed on EVERY rank
+        void *arena = nullptr;
+        size_t bytes = 0;
+        std::vector<void *> peer;             // opened arenas of the other ranks (own slot: nullptr)
+        unsigned long long epoch[3] = {0, 0, 0};
+        double *msg[3] = {nullptr, nullptr, nullptr};   // this rank's three messages inside the arena
+        size_t ext_off = 0, ext_bytes = 0;    // tail of the arena: the persistent kernel's record table + tagged vector rows (cg_persist.hpp, SHARD)
+        size_t ext_ll_bytes = 0;
+        std::string note;                     // why the peer-to-peer transport is unavailable (empty: available or not tried)
+    } p2p;
+    bool p2p_use = false;                     // transport of the CURRENT X-solve (select_transport)
+    DevBuf<PeerTable> peer_table;
+    std::vector<uint64_t> tbounds;            // tile-aligned timestamp partition of the time-sharded CG
+    bool ts_possible = false;
+    // Form of the multi-GPU X-solve: the CG replicated on every rank, or sharded over time with the
+    // per-launch exchange through the communicator or peer to peer.  Forced by TRMF_CG, else measured once: every candidate
+    // runs two X phases (the second timed on every rank), the slowest rank's time decides.  The peer-to-peer transport is
+    // a candidate whenever its set-up (IPC arenas + a trial exchange with a short bound) succeeded on every rank.
+    enum { kXRep = 0, kXTsComm = 1, kXTsP2p = 2, kXTsPersist = 3, kXForms = 4 };
+    int x_form = kXRep;                       // the decided form; -1 while the candidates are being measured
+    std::vector<int> x_cands;
+    int x_calls = 0, cg_pred = 4;
+    float x_ms[kXForms] = {0, 0, 0, 0};       // X phase of the measured call of each candidate (this rank)
+    double x_ms_all[kXForms] = {0, 0, 0, 0};     // ... the slowest rank's (after the decision)
+    hipEvent_t ts0 = nullptr, ts1 = nullptr;
+    int ar_TI = 64, nbar = 1;                 // unfused path: timestamps per ar_tile_kernel workgroup, its partial-sum slots
+    DevBuf<real> arbase;                      // lambdaI*v + lambdaAR*AR'(v) between ar_tile_kernel and apply_kernel
+    XParams xp{};
+    // Knobs that exist for the tests and the measurement scripts (forced failures, forced forms, ablations) are read only when
+    // TRMF_TEST is set; INTEGRATION.md lists the production knobs.
+    static bool test_knobs() { static const bool on = getenv("TRMF_TEST") != nullptr; return on; }
+    static const char *test_env(const char *name) { return test_knobs() ? getenv(name) : nullptr; }
+
+    // base of the partial-sum arrays: the session's own buffer, or -- peer-to-peer time-sharded unfused CG -- message 1 of the arena
+    double *pbase_override = nullptr;
+    // sum of squares of a device value array, fp64 (fixed order): the kernel is enqueued here, the partial sums are read by
+    // finish_sum_squares() after the caller's next synchronisation of the stream
+    static constexpr int kSumsqBlocks = 1024;
+    DevBuf<double> sumsq_part;
+
+    // Host copies of the two pointer arrays (8 bytes per row/column): row partitions, the byte model of
+    // fsolve_bytes(), and the merged pointers of append_rows() are derived from them.
+    std::vector<uint64_t> host_row_ptr, host_col_ptr;
+    double ysq_acc = 0;          // sum of y^2 over every entry uploaded so far (fp64)
+
+    // ---- set-up (trmf_session_create; the first part of every c_trmf_train call) ----------------------------------------
+    // Everything is enqueued on the session's stream and the host waits ONCE, at the end: the caller's arrays travel through the
+    // library's pinned ring (device_pool.hpp), the 64-bit pointers are narrowed on the way, the factors are padded / interleaved
+    // and sum y^2 is formed on the device; device memory comes from the process-level pool, the stream from the stream cache.
+    // Round 4 took 0.12 s for config 3 here (a hipMalloc + a synchronous pageable hipMemcpy per array, ~10 stream
+    // synchronisations, ~30 hipFree at the end); profiles/r05_oneshot.txt has the split now.
+    double t_upload_s = 0;       // seconds of create() spent reading the caller's arrays (TrmfTrainProfile.upload_s)
+    double bytes_uploaded = 0;
+    DevBuf<real> raw_W, raw_H;   // unpadded factor uploads: alive until the set-up's synchronisation
+    static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    bool created = false;        // create() has finished: append_rows() re-tunes, alloc_time_scratch() inside create() does not
+
+    static double sum_squares(const real *v, uint64_t count) {
+        double acc = 0;
+        for (uint64_t e = 0; e < count; e++) acc += (double)v[e] * (double)v[e];
+        return acc;
+    }
+    // rows of a dense PyMatrix (either memory order) as one row-major block; returns the sum of squares
+    static double dense_rows_to_rowmajor(const PyMatrix *Y, std::vector<real> &tn) {
+        const size_t R = Y->rows, C = Y->cols;
+        const real *v = (const real *)Y->val;
+        tn.resize(R * C);
+        double acc = 0;
+        if (Y->type == TRMF_DENSE_ROWMAJOR) {
+            std::memcpy(tn.data(), v, R * C * sizeof(real));
+            for (size_t e = 0; e < R * C; e++) acc += (double)v[e] * (double)v[e];
+        } else {
+            for (size_t j = 0; j < R; j++)
+                for (size_t i = 0; i < C; i++) { const real y = v[i * R + j]; tn[j * C + i] = y; acc += (double)y * (double)y; }
+        }
+        return acc;
+    }
+    void launch_transpose(const real *src, int rows, int cols, real *dst) {
+        if (rows > 0 && cols > 0)
+            hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, stream, src, rows, cols, dst);
+    }
+    // full: do_dot_product(Y, Y) in val_type (trmf.cpp:184); observed-entries path: kept in double, it is the
+    // constant of  loss(w) = sum y^2 + sum_i (w_i^T G_i w_i - 2 b_i.w_i)
+    void set_trYTY() { trYTY = (full || dense) ? (double)(real)ysq_acc : ysq_acc; xp.trYTY = trYTY; }
+
+    // ---- per-series affine transform of a resident dense Y (trmf_session_set_series_transform) -------------------------
+    // rolling_validate(transform=True) -- the paper scripts' setting -- refits a NormalizedTransform on every growing
+    // prefix (trmf.py:82-96, 237-249), which rescales EVERY entry of Y.  The session therefore keeps the raw matrix and
+    // re-derives both training orientations from it on the device; only the 2n coefficients cross PCIe per window.
+    DevBuf<real> Yraw;
+    DevBuf<real> tr_a, tr_b;
+    DevBuf<double> tr_part;
+    bool has_transform = false;
+    // fp32: four systems per wavefront (fsolve_quad_kernel); fp64: one system per wavefront, factorised in the MFMA
+    // accumulator layout (fsolve_mfma_kernel)
+    // X-side Gram build across ranks: sharded rows + all-gather of G (64 MB at config 3) pays only when a
+    // rank's share of the gather is cheaper than the rows it no longer computes -- true on 8 GPUs, not on 2.
+    // First call measures (kernel and gather time of every rank, exchanged through the communicator so that
+    // all ranks take the same decision); TRMF_GRAMX=shard|replicate overrides.
+    enum { kGramxMeasure = 0, kGramxShard = 1, kGramxReplicate = 2 };
+    int gramx_mode = kGramxMeasure, gramx_calls = 0;
+    hipEvent_t gx0 = nullptr, gx1 = nullptr, gx2 = nullptr;
+    DevBuf<double> gramx_times;
+    int dbg_flags = 0;           // TRMF_DEBUG_ABLATE: bit0 skip Gram, bit1 skip factorisation, bit2 skip back-solve
+    // Sharding a phase over the ranks pays only when the all-gather of its result costs less than the rows a rank no
+    // longer computes (true for the F-solve at config 3 on 4 and 8 GPUs, not on 2).  Measure-once rule, shared by the
+    // F-solve and the X-side Gram build: the first two calls run sharded, the second is timed on every rank (kernel, gather); the
+    // times are exchanged through the communicator and every rank takes the same decision.
+    enum { kShardMeasure = 0, kShardOn = 1, kShardOff = 2 };
+    int fs_mode = kShardMeasure, fs_calls = 0;
+    hipEvent_t fs0 = nullptr, fs1 = nullptr, fs2 = nullptr;
+    // Overlapped all-gather of H (large item factors: config 5's is 512 MB): the rank's rows are solved in C launches of
+    // equal nnz; chunk c of every rank's block is gathered on a side stream while launch c + 1 runs, the last chunk follows on
+    // the solver stream, which then waits for the side stream -- only the last chunk's gather is exposed.  C = 2..4 by size
+    // (one chunk per 16 MB of the rank's block); below kOverlapBytes per rank the extra launches' tails cost more than the
+    // gather they hide (config 4).  TRMF_FOVERLAP=0 switches it off, =2..4 forces that many chunks at any size.
+    static constexpr uint64_t kOverlapBytes = 16ull << 20;
+    static constexpr int kMaxChunks = 4;
+    hipStream_t side = nullptr;
+    hipEvent_t ov_b = nullptr, ov_c[kMaxChunks] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint64_t> fcut;               // (world x (chunks + 1)) rows: chunk c of rank r = [fcut[r*(C+1)+c], fcut[r*(C+1)+c+1])
+    int fchunks = 0;
+    // ---- the X-solve as ONE persistent kernel (cg_persist.hpp) ---------------------------------------------------------------
+    // One rank per GPU and the GPU to itself (world == 1): every tile's workgroup stays resident for the whole solve.  Needs all
+    // workgroups co-resident (checked against the occupancy the runtime reports) and the LDS of the resident
+    // vectors; otherwise -- or with TRMF_PERSIST=0 -- the launch-per-step path runs.  Bit-identical results either way.
+    DevBuf<unsigned long long> ll_rec, ll_vec;   // tagged records / tagged vector rows (zero = never a valid tag)
+    DevBuf<long long> persist_prof;           // -DTRMF_PERSIST_PROF builds: phase stamps of the last solve (printed by sync())
+    uint32_t persist_epoch = 1;
+    int persist_state = 0;                    // 0: not examined yet, 1: usable, -1: not
+    template <int KQ, bool SHARD = false> int persist_prepare(size_t lds) {
+        const void *fn = reinterpret_cast<const void *>(&cg_persist_kernel<KQ, SHARD>);
+        if (lds > kLdsMax) return 0;
+        if (lds > kLdsDefault && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        // (256-thread blocks are admitted per CU up to min(API answer, 8, 800 / (ceil(sgprs / 16) * 16 + 16)), same guide: 6 at this
+        // kernel's ~106 SGPRs -- the register-bound answer of 2..3 is always the smaller one; capped anyway)
+        return std::min(per_cu, 4) * prop.multiProcessorCount;
+    }
+    template <int KQ, bool SHARD = false> int persist_launch(const PersistArgs &pa, size_t lds) {
+        // a plain launch: the grid was checked against the occupancy in persist_prepare(); hipLaunchCooperativeKernel gives the same
+        // residency for 15-19 us more host time per launch (MI355X guide, "coop-launch")
+        hipLaunchKernelGGL((cg_persist_kernel<KQ, SHARD>), dim3(SHARD ? tsh_rank.ntiles : nbt), dim3(256), lds, stream, xp, xstate.p, pa);
+        TRMF_HIP_CHECK(hipGetLastError());
+        return 0;
+    }
+    // How many ranks drive the device that hosts the most of them (1 on a real node: one process per GPU).  Persistent kernels of
+    // several processes on ONE device only make progress while all of them are scheduled at once.  Measured with processes standing
+    // in for GPUs (profiles/r04_persist_notes.txt): 2 processes fine; 4 fine while their other kernels are short, but time-sliced to
+    // ~7 s per solve when every rank also runs the full F-solve (a 30 s poll bound lets it finish: slow progress, no lost data); 8
+    // processes ~30 s per solve; even 2 processes occasionally miss the 2 s bound (it won the measurement and then timed out in a later
+    // solve of the full-size test).  Where ranks SHARE a device the measure-once rule therefore leaves that form out (TRMF_CG=persist
+    // still forces it); with a device per rank every poll stays bounded (2 s) and a trial that times out only loses the candidate.
+    int max_ranks_per_device = 1;
+    // several ranks: every rank's tiles in one persistent kernel, tables in the IPC arenas (cg_persist.hpp, SHARD)
+    int persist_shard_state = 0;
+    bool persist_failed = false;
+    std::string persist_note;
+    // Multi-GPU, unfused path: shard the cached-Gram product of every CG step.  It pays when the
+    // rows a rank no longer streams (T k^2 s (1 - 1/N) bytes at ~4 TB/s) outweigh an all-gather of T KP s bytes per
+    // step (latency ~40 us + bytes over the rank's xGMI links); the fused one-launch-per-step path is faster
+    // replicated at the sizes it covers.  TRMF_CG=shard|replicate overrides.
+    bool cg_shard = false;
+    static constexpr int kShardSlots = 4096;
+    int apply_slots = 1;         // partial-sum slots (= workgroups of apply_kernel) per rank when sharded
+    // Time-sharded UNFUSED CG (round 3): like the fused path's, a rank owns a contiguous block of AR
+    // tiles -- its timestamps -- and runs every kernel of the solve on that block only: ar_tile_kernel (vector updates, AR
+    // operator), apply_kernel (cached-Gram product), the element-wise kernels.  Per step the ranks exchange the midx first /
+    // last rows of d, r and H d (edge_pack_kernel -> one all-gather of equal slots -> halo_unpack_kernel) and their slots of
+    // the partial-sum arrays, in one grouped round; nothing T-sized is gathered (the sharded Gram product above gathers the
+    // rows of H d, T KP values, every step).  The host follows the CG's stop as in the fused path.
+    bool uts = false;
+    TileShard ush{};                          // rank / world / rows / edge-slot geometry (no records: the unfused kernels keep arrays)
+    std::vector<uint64_t> ubounds;            // AR-tile-aligned timestamp partition
+    DevBuf<double> umsg;                      // edge message: world slots of 2 sides x 3 vectors x midx rows
+    double *umsg_ptr = nullptr;               // = umsg.p (communicator transport)
+    unsigned u_exchanges = 0;                 // peer to peer: exchanges issued so far (selects the edge message, 0 or 2)
+    int u_tile0 = 0, u_ntiles = 0, u_tpr = 0, wn_slots = 1;
+    // one grouped exchange of the time-sharded unfused CG: edge rows of nvec vectors + this rank's slots of partial arrays
+    // (kind 0: apply_kernel's slots, 1: ar_tile_kernel's, 2: wnew_kernel's)
+    struct PartialRef { int slot, kind; };
+
+    hipEvent_t xg1_event = nullptr;           // this iteration's PhaseEvents::xg1 (set by run())
+
+    // Dynamic LDS above the 64 KB every launch may use needs an explicit opt-in per kernel (gfx950: up to 160 KB
+    // per workgroup); anything larger is an unsupported problem, reported instead of a failed launch.
+    static constexpr size_t kLdsDefault = 64 * 1024, kLdsMax = 160 * 1024;
+    template <typename Fn> int allow_dyn_lds(Fn fn, size_t bytes, const char *what) {
+        if (bytes <= kLdsDefault) return 0;
+        if (bytes > kLdsMax) { set_error(std::string(what) + ": needs more than 160 KB of LDS per workgroup"); return kFail; }
+        TRMF_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        return 0;
+    }
+
+    // ---- measure-once decisions, taken BEFORE the first iteration --------------------------------------------------------
+    // With several ranks three things are decided by measurement (F rows sharded or not, X-side Gram rows sharded or not, the
+    // form of the X-solve); each needs a couple of ordinary iterations and host synchronisations.  autotune() runs those
+    // iterations right after the session is built (and after append_rows, which changes the geometry) on the real problem,
+    // then puts W, H and Theta back and resets the iteration counter: the ALS loop proper never synchronises with the host,
+    // and its timed window -- wherever a caller places it -- contains no measuring iterations.  Every form
+    // computes the same iterates, so the decisions change speed only.  TRMF_AUTOTUNE=0 leaves the decisions to the first
+    // iterations of run() as in round 3.
+    static constexpr int kAutotuneMax = 14;
+    int tuned_iters = 0;
+    bool decisions_from_cache = false;
+
+    // ---- recovery when the persistent kernel's co-residency assumption breaks (one rank; VERDICT / ADVICE r4) -----------------
+    // The one-GPU X-solve is ONE kernel whose workgroups wait for each other; if something else holds compute units (a second
+    // process on the GPU) a poll runs into its bound, the kernel ends with XState::p2p_error set and every later persistent
+    // launch returns at once.  The iterates since then are void -- and a timeout in the last exchange can leave W half-updated
+    // -- so the session keeps a snapshot of (W, H, Theta, iteration counter) as of its last CHECKED synchronisation: sync()
+    // restores it, switches to the launch-per-step path (bit-identical iterates, no co-residency needed) for the rest of the
+    // session's life and repeats the iterations since the snapshot.  Cost: three device-to-device copies per sync()
+    // (18 MB at config 3, ~10 us), only while the persistent kernel is in use.
+    DevBuf<real> snapW, snapH, snapT;
+    int snap_iter = -1;
+};
+
+}  // namespace trmf

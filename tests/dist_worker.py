@@ -93,8 +93,12 @@ def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None, dtyp
         # which no longer exists): same result
         again = make_model(W0, H0, T0, p['lag_set'])
         with session.Session(Y, again, missing=True, **synth.HYPER) as s:
-            s.run(iters); s.download()
+            s.run(iters); s.download(); desc2 = s.describe()
         same = bool(np.array_equal(again.W, model.W) and np.array_equal(again.H, model.H) and np.array_equal(again.lag_val, model.lag_val))
+        # ... and it takes the first session's measure-once decisions from the process-level cache instead of measuring again
+        # (round 5: what the second c_trmf_train call of a grid_search sees)
+        if 'decided in' in desc and 'decided in 0 set-up' not in desc and os.environ.get('TRMF_AUTOTUNE') != '0':
+            same = same and '(cached)' in desc2 and desc2.split('; decided')[0] == desc.split('; decided')[0]
         tdist.finalize(dtype)
         phases = [(x['ms_F'], x['ms_F_kernel'], x['ms_X'], x['ms_LV']) for x in st]
         if shape == 'c3full':       # the factors of the full problem stay in the worker: digests + a sample travel

@@ -95,6 +95,54 @@ def test_config3_full_size_vs_reference_build():
     assert all(abs(a - b) <= 1 for a, b in zip(cg_p, cg_g))       # the restatement's CG counts are pinned to the reference's (goldens)
 
 
+def test_config3_fp64_10_iterations_vs_reference_build():
+    """north_star's horizon at the headline size, where it can be shown: config 3's workload in fp64, TEN ALS iterations from the
+    random start on the GPU's fp64 library against the real reference's fp64 build.  In fp32 the truncated CG amplifies rounding
+    differences from iteration to iteration (the reference's own fp32 build drifts 1.5e-4 from its line-by-line restatement by
+    iteration 10, profiles/r02_fp32_trajectory_c3.txt), so the fp32 tests compare over two iterations; fp64 has no such noise floor
+    and both builds exist: objective 1e-8, factors 1e-6 (max-rel), CG counts EQUAL to the ones the reference prints on its TRON
+    line (rf_tron.h:219).  Printed, not gated: how far the fp32 GPU run and the fp32 reference run are from that common fp64
+    trajectory after the same ten iterations."""
+    import re
+    from helpers import capture_fds
+    if O.ref(np.float64) is None:
+        pytest.skip('oracle/_ref not built (make -C oracle ref, build container only; the .so files travel with gpurun)')
+    cfg = synth.CONFIGS['c3']
+    p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float64, seed=0)
+    Y, lags = p['Y'], p['lag_set']
+    m0 = synth.initial_model(Y, lags, cfg['k'], seed=0, dtype=np.float64)
+    iters, threads = 10, 8                     # 8 threads: the reference's fastest setting on this host (posv inside OpenMP, bench.py)
+    W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+    with capture_fds() as cap:
+        O.train_ref(Y, lags, W, H, Th, synth.HYPER, max_iter=iters, threads=threads, verbose=2)
+    cg_ref = [int(m.group(1)) for l in cap.out for m in [re.search(r'CG\s+(\d+)', l)] if m]
+    model = make_model(m0.W, m0.H, m0.lag_val, lags)
+    with session.Session(Y, model, missing=True, **synth.HYPER) as s:
+        s.run(iters); st = s.stats(iters); s.download()
+    Jr = O.objective(Y, lags, W, H, Th, synth.HYPER)
+    Jg = O.objective(Y, lags, model.W, model.H, model.lag_val, synth.HYPER)
+    cg_gpu = [x['cg_iter'] for x in st]
+    evidence('config 3 in fp64, 10 iterations vs the reference build: J ref %.14g gpu %.14g rel %.2e; relmax W %.2e H %.2e Theta %.2e; '
+             'CG reference %s gpu %s' % (Jr, Jg, abs(Jg - Jr) / Jr, relmax(model.W, W), relmax(model.H, H), relmax(model.lag_val, Th), cg_ref, cg_gpu))
+    assert abs(Jg - Jr) / Jr < 1e-8
+    assert relmax(model.W, W) < 1e-6 and relmax(model.H, H) < 1e-6 and relmax(model.lag_val, Th) < 1e-6
+    assert len(cg_ref) == iters and cg_gpu == cg_ref
+    # the fp32 runs against this fp64 trajectory (printed only: the noise floor of the truncated fp32 CG, not an implementation error)
+    Y32 = Y.astype(np.float32)
+    W32, H32, T32 = m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32))
+    g32 = make_model(W32, H32, T32, lags)
+    with session.Session(Y32, g32, missing=True, **synth.HYPER) as s:
+        s.run(iters); s.download()
+    line = 'config 3 after 10 iterations, distance to the fp64 trajectory (objective rel / relfro W / relfro H): fp32 GPU %.2e / %.2e / %.2e' % (
+        abs(O.objective(Y, lags, g32.W, g32.H, g32.lag_val, synth.HYPER) - Jr) / Jr, relfro(g32.W, W), relfro(g32.H, H))
+    if O.ref(np.float32) is not None:
+        O.train_ref(Y32, lags, W32, H32, T32, synth.HYPER, max_iter=iters, threads=threads)
+        line += '; fp32 reference %.2e / %.2e / %.2e; fp32 GPU vs fp32 reference %.2e (objective)' % (
+            abs(O.objective(Y, lags, W32, H32, T32, synth.HYPER) - Jr) / Jr, relfro(W32, W), relfro(H32, H),
+            abs(O.objective(Y, lags, g32.W, g32.H, g32.lag_val, synth.HYPER) - O.objective(Y, lags, W32, H32, T32, synth.HYPER)) / Jr)
+    evidence(line)
+
+
 def test_config5_full_size_single_gpu_vs_oracle():
     """1M x 50k, 0.1 %, k=64, |L|=32, fp64 on one GPU (HBM capacity + the fp64 rank-64 kernels + T = 50k in
     the CG): one ALS iteration vs the restatement on all host cores, fp64 gates."""
