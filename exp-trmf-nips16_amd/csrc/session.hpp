@@ -9,6 +9,8 @@
 
 #include "session_xphase.hpp"
 
+extern "C" char **environ;      // (the TRMF_* environment is part of the key of the decision cache)
+
 namespace trmf {
 
 struct TrmfSessionImpl : SessionXPhase {
@@ -466,8 +468,7 @@ struct TrmfSessionImpl : SessionXPhase {
         std::string key = std::to_string(T) + "," + std::to_string(n) + "," + std::to_string(k) + "," + std::to_string(nnz) + "," + std::to_string(nlag) + "," +
                           std::to_string(midx) + "," + std::to_string(sizeof(real)) + "," + std::to_string(full) + std::to_string(dense) + "," + std::to_string(comm->id) + "," +
                           std::to_string(comm->world) + "," + std::to_string(period_W > 0) + std::to_string(period_H > 0);
-        extern char **environ;
-        for (char **e = environ; e && *e; e++) if (!strncmp(*e, "TRMF_", 5)) { key += ";"; key += *e; }
+        for (char **e = ::environ; e && *e; e++) if (!strncmp(*e, "TRMF_", 5)) { key += ";"; key += *e; }
         return key;
     }
     int autotune() {
