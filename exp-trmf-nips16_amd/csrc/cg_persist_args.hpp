@@ -46,6 +46,58 @@ __host__ __device__ inline size_t persist_lds_bytes(int TI, int midx, int KP, in
     return 3 * vec + 2 * own + res + th + (size_t)tiles * 4 * sizeof(double);             // + the collected records
 }
 
+// ---- measurement aid: the peers of a rank's persistent SHARD kernel, emulated by ONE workgroup (solo communicator, loop-back) ----
+// VERDICT r4 item 2 asks what ONE rank's persistent kernel costs per CG step at N-way sharding with the GPU to itself.  The kernel
+// itself is left exactly as it ships (it runs at the limit of its registers; a "count the others as arrived" switch inside it cost
+// spills): instead this kernel plays every other rank on a side stream.  For exchange x = 0, 1, ... it waits until the rank's first
+// tile has published its record of x, then stores the records of all foreign tiles and the neighbouring ranks' halo rows of x
+// (payload zero, the right tag) into the rank's own tables -- a peer that answers one memory round trip after it has been
+// spoken to.  It ends when the host writes this solve's epoch into `done` (after the rank's kernel has finished).
+struct PeerEmuArgs {
+    unsigned long long *ll, *hll;      // the rank's own record / row tables (cg_persist_kernel's)
+    unsigned long long *done;          // ends the kernel when it holds epoch0
+    uint32_t epoch0;
+    int nbt, tile0, ntiles, row_b, row_e, T, KP, midx, max_x, elem_bytes;
+};
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
+__global__ void store_u64_kernel(unsigned long long *dst, unsigned long long v) { __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__global__ __launch_bounds__(256) void persist_peer_emulator_kernel(PeerEmuArgs a) {
+    const int tid = threadIdx.x;
+    const size_t hll_elems = (size_t)a.T * a.KP;
+    const int EB = 2 * a.elem_bytes;                       // tagged bytes per element
+    __shared__ int s_go;
+    for (int x = 0; x <= a.max_x; x++) {
+        const uint32_t tag = a.epoch0 + (uint32_t)x;
+        if (tid == 0) {
+            const unsigned long long *rec = a.ll + ((size_t)(x & 1) * a.nbt + a.tile0) * kLLWords;
+            int go = 0;
+            for (;;) {
+                if ((uint32_t)(__hip_atomic_load(rec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32) == tag) { go = 1; break; }
+                if (__hip_atomic_load(a.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == (unsigned long long)a.epoch0) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            s_go = go;
+        }
+        __syncthreads();
+        if (!s_go) return;
+        const unsigned long long tw = (unsigned long long)tag << 32;
+        for (int t = tid; t < a.nbt; t += 256) {
+            if (t >= a.tile0 && t < a.tile0 + a.ntiles) continue;
+            unsigned long long *rec = a.ll + ((size_t)(x & 1) * a.nbt + t) * kLLWords;
+            for (int q = 0; q < kLLWords; q++) __hip_atomic_store(rec + q, tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        // halo rows: midx rows below row_b and above row_e, in 8-byte tagged words {payload half / element, tag}
+        const int words_per_row = a.KP * EB / 8;
+        for (int side = 0; side < 2; side++) {
+            const int r0 = side == 0 ? max(0, a.row_b - a.midx) : a.row_e, r1 = side == 0 ? a.row_b : min(a.T, a.row_e + a.midx);
+            unsigned long long *base = reinterpret_cast<unsigned long long *>(reinterpret_cast<unsigned char *>(a.hll) + ((size_t)(x & 1) * hll_elems + (size_t)r0 * a.KP) * EB);
+            for (int w = tid; w < (r1 - r0) * words_per_row; w += 256) __hip_atomic_store(base + w, tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+    }
+}
+#endif
+
 template <int KQ, bool SHARD>
 __global__ void cg_persist_kernel(XParams p, XState *__restrict__ st, PersistArgs a);      // defined in cg_persist.hpp, instantiated in unit_persist.hip
 

@@ -47,6 +47,7 @@ struct Comm {
     // Gather in place with EQUAL slots: rank r owns bytes [r * slot, (r + 1) * slot) of dbuf.  No staging, no unpack:
     // the per-step exchange of the time-sharded CG (one message slot per rank: tile records + edge rows).
     virtual int allgather_slots(void *dbuf, size_t slot_bytes, hipStream_t stream) = 0;
+    virtual bool solo() const { return false; }      // SoloComm: rank r of N without peers (measurement aid)
 };
 
 // ---- equal-slot staging shared by the communicators -----------------------------------------------
@@ -137,9 +138,15 @@ struct SelfComm : Comm {
 // Measurement aid: rank r of a world of N with NO peers -- every gather is skipped.  A session under it runs exactly the
 // kernels rank r would run (its item rows, its timestamps, its tiles) with the GPU to itself, so their times are a rank's
 // compute share undisturbed by other processes; the factors it produces are NOT a solution (the other ranks' blocks are stale).
+// The persistent-kernel form of the time-sharded CG (TRMF_CG=persist) runs under it in LOOP-BACK: the "peers' arenas" are this
+// rank's own arena, and one workgroup on a side stream plays the other ranks (persist_peer_emulator_kernel, cg_persist_args.hpp):
+// the rank's kernel -- unchanged -- does all of ITS work (its tiles' chain, the poll of the full record table, its publishes into
+// N table copies) and is answered one memory round trip later: the per-step cost of a rank at N-way sharding, measured alone
+// (VERDICT r4 item 2).
 struct SoloComm : Comm {
     int allgatherv_ranges(void *, const uint64_t *, const uint64_t *, hipStream_t) override { return 0; }
     int allgather_slots(void *, size_t, hipStream_t) override { return 0; }
+    bool solo() const override { return true; }
 };
 
 struct CallbackComm : Comm {

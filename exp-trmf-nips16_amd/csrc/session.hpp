@@ -24,7 +24,7 @@ struct TrmfSessionImpl : SessionXPhase {
         }
         for (hipEvent_t ev : {gx0, gx1, gx2, fs0, fs1, fs2, ts0, ts1}) if (ev) (void)hipEventDestroy(ev);
         release_p2p();
-        for (hipEvent_t ev : {ov_b, ov_c[0], ov_c[1], ov_c[2], ov_c[3]}) if (ev) (void)hipEventDestroy(ev);
+        for (hipEvent_t ev : {ov_b, ov_c[0], ov_c[1], ov_c[2], ov_c[3], emu_ready, emu_end}) if (ev) (void)hipEventDestroy(ev);
         if (side) (void)hipStreamDestroy(side);
         StreamCache::release(stream);
     }

@@ -80,6 +80,7 @@ struct SessionState {
     // this rank in one IPC-exported arena, the peers' arenas opened, the pointer table in device memory
     struct P2p {
         bool on = false;                      // arena allocated, exported, mapped by every peer, and the trial exchange passed on EVERY rank
+        bool loopback = false;                // solo communicator: the peers' pointers are this rank's own arena (never IPC-opened)
         void *arena = nullptr;
         size_t bytes = 0;
         std::vector<void *> peer;             // opened arenas of the other ranks (own slot: nullptr)
@@ -198,6 +199,7 @@ struct SessionState {
     static constexpr uint64_t kOverlapBytes = 16ull << 20;
     static constexpr int kMaxChunks = 4;
     hipStream_t side = nullptr;
+    hipEvent_t emu_ready = nullptr, emu_end = nullptr;     // loop-back measurement under the solo communicator (xsolve_persist)
     hipEvent_t ov_b = nullptr, ov_c[kMaxChunks] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<uint64_t> fcut;               // (world x (chunks + 1)) rows: chunk c of rank r = [fcut[r*(C+1)+c], fcut[r*(C+1)+c+1])
     int fchunks = 0;

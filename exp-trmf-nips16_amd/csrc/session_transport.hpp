@@ -11,7 +11,8 @@ namespace trmf {
 
 struct SessionTransport : SessionState {
     void release_p2p() {
-        for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
+        if (!p2p.loopback) for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
+        p2p.loopback = false;
         p2p.peer.clear();
         if (p2p.arena) (void)hipFree(p2p.arena);
         p2p.arena = nullptr; p2p.on = false; p2p_use = false; pbase_override = nullptr;
@@ -46,6 +47,35 @@ struct SessionTransport : SessionState {
         };
         p2p.note.clear();
         if (W_ > kMaxPeers) return unavailable("more than 8 ranks");
+        if (comm->solo()) {
+            // loop-back (SoloComm): one uncached arena, every "peer" pointer is this rank's own copy; no handles, no trial.  Only the
+            // persistent-kernel form runs on it (its solo mode waits for nobody); the launch-per-step exchanges would wait for flags
+            // no peer raises, so without TRMF_CG=persist the transport stays unavailable as before.
+            const char *e = getenv("TRMF_CG");
+            if (!(e && e[0] == 'p' && e[1] == 'e')) return unavailable("no peers under the solo communicator");
+            const size_t msg_bytes = (msg_doubles * sizeof(double) + 255) / 256 * 256, flag_bytes = (size_t)3 * W_ * kFlagStride * sizeof(unsigned long long);
+            p2p.ext_off = (3 * msg_bytes + flag_bytes + 255) / 256 * 256;
+            p2p.ext_ll_bytes = (ext_ll_bytes + 255) / 256 * 256;
+            p2p.ext_bytes = p2p.ext_ll_bytes + ext_hll_bytes;
+            p2p.bytes = p2p.ext_off + p2p.ext_bytes;
+            if (hipExtMallocWithFlags(&p2p.arena, p2p.bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); p2p.arena = nullptr; return unavailable("no uncached arena"); }
+            TRMF_HIP_CHECK(hipMemsetAsync(p2p.arena, 0, p2p.bytes, stream));
+            p2p.peer.assign(W_, nullptr);
+            p2p.loopback = true;
+            PeerTable tab{};
+            for (int r = 0; r < W_; r++) {
+                unsigned char *base = (unsigned char *)p2p.arena;
+                if (r != me) p2p.peer[r] = p2p.arena;
+                for (int m = 0; m < 3; m++) {
+                    tab.msg[m][r] = reinterpret_cast<double *>(base + m * msg_bytes);
+                    tab.flags[m][r] = reinterpret_cast<unsigned long long *>(base + 3 * msg_bytes) + (size_t)m * W_ * kFlagStride;
+                }
+            }
+            if (peer_table.upload(&tab, 1)) return kFail;
+            for (int m = 0; m < 3; m++) { p2p.msg[m] = tab.msg[m][me]; p2p.epoch[m] = 0; }
+            p2p.on = true;
+            return 0;
+        }
         constexpr size_t kSlot = 128;                                     // [0..63] IPC handle, [64] ok flag
         static_assert(sizeof(hipIpcMemHandle_t) <= 64, "IPC handle slot");
         DevBuf<unsigned char> slots;

@@ -326,9 +326,30 @@ struct SessionXPhase : SessionFPhase {
         }
 #endif
         const size_t lds = persist_lds_bytes(tile_TI, midx, KP, nlag, k, nbt);
+        unsigned long long *emu_done = nullptr;
+        if (shard && comm->solo()) {
+            // loop-back measurement (solo communicator): one workgroup on the side stream plays the other ranks
+            if (!side) TRMF_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            if (!emu_ready) { TRMF_HIP_CHECK(hipEventCreateWithFlags(&emu_ready, hipEventDisableTiming)); TRMF_HIP_CHECK(hipEventCreateWithFlags(&emu_end, hipEventDisableTiming)); }
+            PeerEmuArgs ea{};
+            ea.ll = pa.ll; ea.hll = pa.hll; ea.epoch0 = pa.epoch0; ea.nbt = nbt; ea.tile0 = tsh_rank.tile0; ea.ntiles = tsh_rank.ntiles;
+            ea.row_b = tsh_rank.row_b; ea.row_e = tsh_rank.row_e; ea.T = T; ea.KP = KP; ea.midx = midx; ea.max_x = maxcg + 6; ea.elem_bytes = (int)sizeof(real);
+            // the done word: the first flag word of the arena's message area (unused by the persistent form)
+            emu_done = reinterpret_cast<unsigned long long *>((unsigned char *)p2p.arena + p2p.ext_off - 256);
+            ea.done = emu_done;
+            TRMF_HIP_CHECK(hipEventRecord(emu_ready, stream));               // everything the solve reads is in place
+            TRMF_HIP_CHECK(hipStreamWaitEvent(side, emu_ready, 0));
+            hipLaunchKernelGGL(persist_peer_emulator_kernel, dim3(1), dim3(256), 0, side, ea);
+            TRMF_HIP_CHECK(hipGetLastError());
+        }
 #define TRMF_PERSIST_GO(KQV) if (shard ? persist_launch<KQV, true>(pa, lds) : persist_launch<KQV, false>(pa, lds)) return kFail
         TRMF_PERSIST_SWITCH(TRMF_PERSIST_GO)
 #undef TRMF_PERSIST_GO
+        if (emu_done) {
+            hipLaunchKernelGGL(store_u64_kernel, dim3(1), dim3(1), 0, stream, emu_done, (unsigned long long)pa.epoch0);   // ends the emulator
+            TRMF_HIP_CHECK(hipEventRecord(emu_end, side));
+            TRMF_HIP_CHECK(hipStreamWaitEvent(stream, emu_end, 0));           // the next solve's tables are not touched by a late emulator
+        }
         // the F-solve gathers rows of all of W -- and this collective is what keeps a fast rank's next solve out of the record
         // slots a slow rank is still polling (cg_persist.hpp, "Across launches")
         if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;

@@ -13,10 +13,7 @@ import sys
 
 HOT = ('fsolve_', 'gram_x_kernel', 'hv_tile_kernel', 'cg_persist_kernel', 'apply_kernel', 'ar_tile_kernel', 'loss_kernel', 'apply_shared_mfma_kernel',
        'theta_', 'dense_tn_mfma_kernel', 'small_gram_mfma_kernel', 'cg_close_kernel')
-ALLOW = {
-    # round-2 fp64 F-solve, selectable with TRMF_FSOLVE=grid for comparison only (fsolve_mfma_kernel is the fp64 path)
-    'fsolve_grid_kernel': 'kept as a measured alternative (TRMF_FSOLVE=grid), 14 doubles of scratch by design (DESIGN.md 4.3)',
-}
+ALLOW = {}
 
 
 def demangle(names):
