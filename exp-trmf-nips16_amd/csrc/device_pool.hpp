@@ -191,7 +191,7 @@ class HostStager {
 public:
     static constexpr size_t kChunk = (size_t)4 << 20;
     static constexpr int kSlots = 6, kThreads = 2;
-    static constexpr size_t kStagingCap = (size_t)256 << 20;      // larger downloads stage through ordinary host memory
+    static constexpr size_t kStagingCap = (size_t)1 << 30;      // larger downloads stage through ordinary host memory (config 5: 538 MB)
     static HostStager &current() {              // one per device (its events belong to that device)
         static std::mutex mu;
         static std::map<int, HostStager *> all;
@@ -279,13 +279,23 @@ public:
         }
         return stage_;
     }
+    void release_staging() {
+        std::lock_guard<std::mutex> lk(stage_mu_);
+        if (stage_) (void)hipHostFree(stage_);
+        stage_ = nullptr; stage_cap_ = 0;
+    }
     // host copy with the stager's worker count (committing staged outputs into the caller's arrays)
     static void parallel_copy(void *dst, const void *src, size_t bytes) {
         if (bytes < ((size_t)4 << 20)) { std::memcpy(dst, src, bytes); return; }
-        const size_t half = (bytes / 2 + 63) / 64 * 64;
-        std::thread t([&] { std::memcpy((unsigned char *)dst + half, (const unsigned char *)src + half, bytes - half); });
-        std::memcpy(dst, src, half);
-        t.join();
+        const int parts = bytes >= ((size_t)64 << 20) ? 4 : 2;
+        const size_t piece = (bytes / parts + 63) / 64 * 64;
+        std::vector<std::thread> th;
+        for (int q = 1; q < parts; q++) {
+            const size_t off = std::min(bytes, q * piece), len = std::min(bytes, (q + 1) * piece) - off;
+            if (len) th.emplace_back([=] { std::memcpy((unsigned char *)dst + off, (const unsigned char *)src + off, len); });
+        }
+        std::memcpy(dst, src, std::min(bytes, piece));
+        for (auto &t : th) t.join();
     }
     std::atomic<uint64_t> bytes_h2d{0};
 

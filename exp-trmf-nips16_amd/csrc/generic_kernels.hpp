@@ -14,7 +14,7 @@
 
 namespace trmf {
 
-constexpr int kMaxRankGeneric = 1024;    // the k x k scratch slots and the 160 KB of LDS bound it, nothing else does
+constexpr int kMaxRankGeneric = 1024;    // the k x k scratch slots in HBM bound it (gram_generic_lds(k): ~37 KB of LDS at rank 1024), nothing else does
 constexpr int kApplyThreadPerColumn = 256;   // apply_kernel: one thread per (timestamp, column) up to here, apply_wide_kernel beyond
 constexpr int kGenChunk = 8;             // observed entries staged per pass
 constexpr int kGenBlocks = 512;          // workgroups (and k x k scratch slots) of the F-solve

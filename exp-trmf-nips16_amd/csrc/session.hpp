@@ -155,12 +155,20 @@ struct TrmfSessionImpl : SessionXPhase {
             if (launch_sum_squares(Yr_val.p, nnz)) return kFail;
             bytes_uploaded += 2.0 * (double)nnz * (4 + sizeof(real)) + 8.0 * ((double)T + n + 2);
         } else {
-            // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC
-            std::vector<real> tn;
-            ysq_acc = dense_rows_to_rowmajor(Y, tn);
-            if (Yd_tn.upload(tn.data(), tn.size()) || Yd_nt.alloc((size_t)T * n, false)) return kFail;
-            launch_transpose(Yd_tn.p, T, n, Yd_nt.p);
-            bytes_uploaded += (double)tn.size() * sizeof(real);
+            // dense Y (only legal with missing == 0): keep both orientations, like CSR + CSC.  The caller's array goes through the
+            // pinned ring as it is -- a column-major T x n array IS the row-major n x T orientation -- the other orientation and
+            // sum y^2 are formed on the device (round 4 made a host copy and a host pass: 27 of config 1's 30 ms per one-shot call)
+            const size_t N = (size_t)T * n;
+            if (Yd_tn.alloc(N, false) || Yd_nt.alloc(N, false)) return kFail;
+            if (Y->type == TRMF_DENSE_ROWMAJOR) {
+                if (HostStager::current().h2d(Yd_tn.p, Y->val, N * sizeof(real), stream)) return kFail;
+                launch_transpose(Yd_tn.p, T, n, Yd_nt.p);
+            } else {
+                if (HostStager::current().h2d(Yd_nt.p, Y->val, N * sizeof(real), stream)) return kFail;
+                launch_transpose(Yd_nt.p, n, T, Yd_tn.p);
+            }
+            if (launch_sum_squares(Yd_tn.p, N)) return kFail;
+            bytes_uploaded += (double)N * sizeof(real);
         }
         if (lag_set.upload(lags, nlag)) return kFail;
         {
@@ -192,8 +200,7 @@ struct TrmfSessionImpl : SessionXPhase {
         if (const char *e = test_env("TRMF_GRAMX")) gramx_mode = (e[0] == 'r') ? kGramxReplicate : kGramxShard;
         if (const char *e = test_env("TRMF_FSHARD")) fs_mode = (e[0] == 'r') ? kShardOff : kShardOn;
         // the set-up's one synchronisation: uploads landed, factors padded, sum y^2 formed
-        if (!dense) { if (finish_sum_squares(&ysq_acc)) return kFail; }
-        else TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        if (finish_sum_squares(&ysq_acc)) return kFail;
         set_trYTY();
         raw_W.release(); raw_H.release(); sumsq_part.release();
         if (comm->world > 1) {
@@ -225,7 +232,9 @@ struct TrmfSessionImpl : SessionXPhase {
             if (theta_scratch.alloc((size_t)k * ((size_t)nlag * nlag + nlag), false)) return kFail;
         } else if (nlag && allow_dyn_lds(theta_solve_kernel, theta_solve_lds(), "Theta solve (too many lags)")) return kFail;
         if (generic) {
-            if (gen_scratch.alloc((size_t)kGenBlocks * k * k, false)) return kFail;
+            // one k x k slot per workgroup of the generic F-solve: min(kGenBlocks, item rows) of them (kGenBlocks * k^2 at rank 1024
+            // was 2 GiB in fp32 / 4 GiB in fp64 whatever the number of rows)
+            if (gen_scratch.alloc((size_t)std::min(kGenBlocks, std::max(n, 1)) * k * k, false)) return kFail;
             if (allow_dyn_lds(gram_generic_kernel<true>, gram_generic_lds(k), "generic F-solve") ||
                 allow_dyn_lds(gram_generic_kernel<false>, gram_generic_lds(k), "generic Gram build")) return kFail;
         }
@@ -403,7 +412,7 @@ struct TrmfSessionImpl : SessionXPhase {
             if (device_sum_squares(val2.p, new_nnz, &new_ysq)) return kFail;
         } else {
             std::vector<real> blk;
-            new_ysq += dense_rows_to_rowmajor(Yn, blk);
+            (void)dense_rows_to_rowmajor(Yn, blk);
             if (tn2.alloc((size_t)T1 * n, false) || nt2.alloc((size_t)T1 * n, false)) return kFail;
             TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p, Yd_tn.p, (size_t)T0 * n * sizeof(real), hipMemcpyDeviceToDevice, stream));
             TRMF_HIP_CHECK(hipMemcpyAsync(tn2.p + (size_t)T0 * n, blk.data(), blk.size() * sizeof(real), hipMemcpyHostToDevice, stream));
@@ -416,6 +425,7 @@ struct TrmfSessionImpl : SessionXPhase {
             TRMF_HIP_CHECK(hipGetLastError());
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));      // blk is a local: its copies must have left the host
             new_nnz = (uint64_t)T1 * n;
+            if (device_sum_squares(tn2.p, new_nnz, &new_ysq)) return kFail;    // over the grown matrix, like a fresh session's
         }
         {   // W: T0 rows kept, Tn rows rolled out by the AR model, one all-zero row at the end
             if (W2.alloc((size_t)(T1 + 1) * KP)) return kFail;

@@ -66,7 +66,7 @@ struct SessionState {
     std::vector<PhaseEvents> events;
     static constexpr int kEventRing = 64;
     int nbe = 1, nba = 1, rpb = 1;            // grids of the elementwise / apply kernels
-    bool generic = false;                     // 64 < k <= 256: generic_kernels.hpp for the Grams / the F-solve, unfused CG
+    bool generic = false;                     // 64 < k <= 1024: generic_kernels.hpp for the Grams / the F-solve, unfused CG
     DevBuf<real> gen_scratch, theta_scratch;  // k x k systems of the generic F-solve; |L| x |L| systems of long lag sets
     bool gpacked = false;                     // unfused path: G holds upper triangles (packed_gram_elems(k) per timestamp), apply_kernel<true>
     int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), tiles of the problem
@@ -142,20 +142,16 @@ struct SessionState {
         for (uint64_t e = 0; e < count; e++) acc += (double)v[e] * (double)v[e];
         return acc;
     }
-    // rows of a dense PyMatrix (either memory order) as one row-major block; returns the sum of squares
+    // rows of a dense PyMatrix (either memory order) as one row-major block (append_rows: one window of new timestamps)
     static double dense_rows_to_rowmajor(const PyMatrix *Y, std::vector<real> &tn) {
         const size_t R = Y->rows, C = Y->cols;
         const real *v = (const real *)Y->val;
         tn.resize(R * C);
-        double acc = 0;
-        if (Y->type == TRMF_DENSE_ROWMAJOR) {
-            std::memcpy(tn.data(), v, R * C * sizeof(real));
-            for (size_t e = 0; e < R * C; e++) acc += (double)v[e] * (double)v[e];
-        } else {
+        if (Y->type == TRMF_DENSE_ROWMAJOR) std::memcpy(tn.data(), v, R * C * sizeof(real));
+        else
             for (size_t j = 0; j < R; j++)
-                for (size_t i = 0; i < C; i++) { const real y = v[i * R + j]; tn[j * C + i] = y; acc += (double)y * (double)y; }
-        }
-        return acc;
+                for (size_t i = 0; i < C; i++) tn[j * C + i] = v[i * R + j];
+        return 0;
     }
     void launch_transpose(const real *src, int rows, int cols, real *dst) {
         if (rows > 0 && cols > 0)

@@ -228,6 +228,7 @@ int32_t trmf_release_cached(void) {
     if (!guard.ok) return kFail;
     DevicePool::current().trim();
     StreamCache::drop_idle();
+    HostStager::current().release_staging();
     return 0;
 }
 
