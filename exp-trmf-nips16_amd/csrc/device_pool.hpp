@@ -18,8 +18,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <set>
 #include <thread>
-#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -27,12 +27,13 @@
 namespace trmf {
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// DevicePool: device allocations of all sessions of this process on one device.  Slabs (one hipMalloc each) are carved by a
-// bump pointer; freed blocks wait in a size-keyed free list and are handed out again to requests of (nearly) their size -- the
-// second call of a grid_search finds every buffer of the first.  Nothing is coalesced while blocks are live; when the last live
-// block goes (no session left) the slabs are reset, and released if they are fragmented or above the cache cap
-// (TRMF_POOL_MAX_MB, default 8192; 0 = plain hipMalloc / hipFree, no caching).  reserve() lets a session announce its footprint
-// so that the first call allocates ONE slab.
+// DevicePool: device allocations of all sessions of this process on one device.  Slabs (one hipMalloc each) are divided into
+// blocks kept in address order; a request takes the smallest free block that fits (best fit, the remainder split off), a freed
+// block merges with its free neighbours -- so the second call of a grid_search finds every buffer of the first, and a long-lived
+// session beside many short ones of changing shapes does not make the pool grow without bound.  When the last live block goes
+// (no session left) slabs above the cache cap (TRMF_POOL_MAX_MB, default 8192; 0 = plain hipMalloc / hipFree, no caching) or
+// fragmented over several slabs are released and the next session gets ONE slab of everything the last one needed.  reserve()
+// lets a session announce its footprint so that the first call allocates one slab.
 // Ordering: a block is reused without any device synchronisation.  Safe because every user of a session's buffers is enqueued
 // on that session's stream (or follows a synchronisation of it), sessions synchronise their stream before they release, and
 // temporaries of asynchronous set-up code are kept until the set-up's final synchronisation.
@@ -45,10 +46,10 @@ public:
         (void)hipGetDevice(&dev);
         std::lock_guard<std::mutex> lk(mu);
         DevicePool *&p = pools[dev];
-        if (!p) p = new DevicePool(dev);      // lives for the process: device memory is returned by the runtime at exit
+        if (!p) p = new DevicePool();         // lives for the process: device memory is returned by the runtime at exit
         return *p;
     }
-    struct Stats { uint64_t hip_mallocs = 0, reused = 0, bumped = 0, live = 0, slab_bytes = 0, slabs = 0; };
+    struct Stats { uint64_t hip_mallocs = 0, reused = 0, live = 0, slab_bytes = 0, slabs = 0; };
 
     void *alloc(size_t bytes) {
         const size_t need = round_up(std::max<size_t>(bytes, 1));
@@ -59,44 +60,70 @@ public:
             st_.hip_mallocs++; st_.live++;
             return p;
         }
-        // a free block of nearly this size (exact for a repeated call): at most 1/8 + 64 KB larger
-        auto it = free_.lower_bound(need);
-        if (it != free_.end() && it->first <= need + need / 8 + (64u << 10)) {
-            void *p = it->second;
-            free_.erase(it);
-            st_.reused++; st_.live++;
-            return p;
+        auto it = free_.lower_bound(std::make_pair(need, (unsigned char *)nullptr));      // best fit
+        if (it == free_.end()) {
+            const size_t want = std::max(need, std::max(hint_, (size_t)(8u << 20)));
+            hint_ = 0;
+            unsigned char *base = nullptr;
+            size_t got = want;
+            if (hipMalloc((void **)&base, want) != hipSuccess) {
+                (void)hipGetLastError();
+                got = need;
+                if (want == need || hipMalloc((void **)&base, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            }
+            st_.hip_mallocs++; st_.slabs++; st_.slab_bytes += got;
+            slabs_.push_back(base);
+            blocks_[base] = Block{got, true, base};
+            it = free_.emplace(got, base).first;
+        } else st_.reused++;
+        unsigned char *p = it->second;
+        free_.erase(it);
+        Block &b = blocks_[p];
+        if (b.size - need >= kSplitMin) {                          // split the remainder off
+            unsigned char *rest = p + need;
+            blocks_[rest] = Block{b.size - need, true, b.slab};
+            free_.emplace(b.size - need, rest);
+            b.size = need;
         }
-        for (Slab &s : slabs_)
-            if (s.bytes - s.used >= need) return carve(s, need);
-        const size_t want = std::max(need, std::max(hint_, (size_t)(8u << 20)));
-        hint_ = 0;
-        Slab s{};
-        if (hipMalloc(&s.base, want) != hipSuccess) {
-            (void)hipGetLastError();
-            if (want == need || hipMalloc(&s.base, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-            s.bytes = need;
-        } else s.bytes = want;
-        st_.hip_mallocs++; st_.slabs++; st_.slab_bytes += s.bytes;
-        slabs_.push_back(s);
-        return carve(slabs_.back(), need);
+        b.free = false;
+        st_.live++;
+        return p;
     }
-    void free(void *p) {
-        if (!p) return;
+    void free(void *ptr) {
+        if (!ptr) return;
         std::lock_guard<std::mutex> lk(mu_);
         st_.live--;
-        if (cap_bytes_ == 0) { (void)hipFree(p); return; }
-        auto it = size_of_.find(p);
-        if (it == size_of_.end()) { (void)hipFree(p); return; }   // not ours (cannot happen)
-        free_.emplace(it->second, p);
-        if (st_.live == 0) quiesce();
+        if (cap_bytes_ == 0) { (void)hipFree(ptr); return; }
+        auto it = blocks_.find((unsigned char *)ptr);
+        if (it == blocks_.end() || it->second.free) { if (it == blocks_.end()) (void)hipFree(ptr); return; }   // not ours (cannot happen)
+        it->second.free = true;
+        auto nx = std::next(it);                                    // merge with the free neighbours of the same slab
+        if (nx != blocks_.end() && nx->second.free && nx->second.slab == it->second.slab && it->first + it->second.size == nx->first) {
+            free_.erase(std::make_pair(nx->second.size, nx->first));
+            it->second.size += nx->second.size;
+            blocks_.erase(nx);
+        }
+        if (it != blocks_.begin()) {
+            auto pv = std::prev(it);
+            if (pv->second.free && pv->second.slab == it->second.slab && pv->first + pv->second.size == it->first) {
+                free_.erase(std::make_pair(pv->second.size, pv->first));
+                pv->second.size += it->second.size;
+                blocks_.erase(it);
+                it = pv;
+            }
+        }
+        free_.emplace(it->second.size, it->first);
+        if (st_.live == 0 && (slabs_.size() > 1 || st_.slab_bytes > cap_bytes_)) {
+            const size_t total = st_.slab_bytes;
+            release_all();
+            if (total <= cap_bytes_) hint_ = total;                 // the next session gets one slab of everything the last one needed
+        }
     }
     // the next slab is at least this large (a session's estimate of its footprint)
     void reserve(size_t bytes) {
         std::lock_guard<std::mutex> lk(mu_);
         if (cap_bytes_ == 0) return;
-        size_t room = 0;
-        for (const Slab &s : slabs_) room = std::max(room, s.bytes - s.used);
+        const size_t room = free_.empty() ? 0 : free_.rbegin()->first;
         if (st_.live == 0 && !slabs_.empty() && room < bytes) release_all();     // idle and too small: one slab of the right size instead
         if (room < bytes) hint_ = std::max(hint_, round_up(bytes));
     }
@@ -110,38 +137,22 @@ public:
     }
 
 private:
-    struct Slab { void *base = nullptr; size_t bytes = 0, used = 0; };
-    explicit DevicePool(int) {
+    struct Block { size_t size; bool free; unsigned char *slab; };
+    static constexpr size_t kSplitMin = 4096;
+    DevicePool() {
         cap_bytes_ = (size_t)8192 << 20;
         if (const char *e = getenv("TRMF_POOL_MAX_MB")) cap_bytes_ = (size_t)std::max(0ll, atoll(e)) << 20;
     }
     static size_t round_up(size_t b) { return (b + 255) / 256 * 256; }
-    void *carve(Slab &s, size_t need) {
-        void *p = (unsigned char *)s.base + s.used;
-        s.used += need;
-        size_of_[p] = need;
-        st_.bumped++; st_.live++;
-        return p;
-    }
-    void quiesce() {            // no live block: every slab is one free range again
-        if (slabs_.size() > 1 || st_.slab_bytes > cap_bytes_) {
-            const size_t total = st_.slab_bytes;
-            release_all();
-            if (total <= cap_bytes_) hint_ = total;            // the next session gets one slab of everything the last one needed
-            return;
-        }
-        free_.clear(); size_of_.clear();
-        for (Slab &s : slabs_) s.used = 0;
-    }
     void release_all() {
-        for (Slab &s : slabs_) (void)hipFree(s.base);
-        slabs_.clear(); free_.clear(); size_of_.clear();
+        for (unsigned char *s : slabs_) (void)hipFree(s);
+        slabs_.clear(); free_.clear(); blocks_.clear();
         st_.slab_bytes = 0; st_.slabs = 0;
     }
     std::mutex mu_;
-    std::vector<Slab> slabs_;
-    std::multimap<size_t, void *> free_;
-    std::unordered_map<void *, size_t> size_of_;
+    std::vector<unsigned char *> slabs_;
+    std::map<unsigned char *, Block> blocks_;                      // every block of every slab, by address
+    std::set<std::pair<size_t, unsigned char *>> free_;            // the free ones, by size
     size_t hint_ = 0, cap_bytes_ = 0;
     Stats st_;
 };

@@ -101,11 +101,12 @@ def test_config3_fp64_10_iterations_vs_reference_build():
     differences from iteration to iteration (the reference's own fp32 build drifts 1.5e-4 from its line-by-line restatement by
     iteration 10, profiles/r02_fp32_trajectory_c3.txt), so the fp32 tests compare over two iterations; fp64 has no such noise floor
     and both builds exist: factors 1e-6 (max-rel), CG counts EQUAL to the ones the reference prints on its TRON line
-    (rf_tron.h:219), objective 5e-8 -- SURVEY 8(d)'s 1e-8 is the gate after ONE iteration (tested on every golden and at config 5's
+    (rf_tron.h:219), objective 1e-7 -- SURVEY 8(d)'s 1e-8 is the gate after ONE iteration (tested on every golden and at config 5's
     full size); over ten iterations of a CG truncated at 10 % the last bits of every Gram (summation order: MFMA chain here,
     scalar loop + LAPACK posv there) and of r^T r (a recurrence here, recomputed there: rf_tron.h:492) are amplified.  Measured:
-    1.7e-8; the reference's own line-by-line restatement, run beside it as the yardstick, lands 2.6e-9 from the reference over the
-    same horizon; the fp32 builds are 1e-4 apart there.  Printed, not gated: how far the fp32 GPU run and the fp32 reference run are from that common fp64
+    1.7e-8.  The yardstick is the reference's own line-by-line restatement run beside it over the same horizon: it lands 2.6e-9 from
+    the reference on 256 OpenMP threads and 1.1e-7 on 64 -- the order of its dot-product reductions alone moves the ten-iteration
+    objective by that much (printed, not gated); the two fp32 builds are 1e-4 apart there.  Gate: 1e-7.  Printed, not gated: how far the fp32 GPU run and the fp32 reference run are from that common fp64
     trajectory after the same ten iterations."""
     import re
     from helpers import capture_fds
@@ -133,7 +134,7 @@ def test_config3_fp64_10_iterations_vs_reference_build():
     Jp = O.objective(Y, lags, Wp, Hp, Tp, synth.HYPER)
     evidence('config 3 in fp64, 10 iterations: the restatement against the reference build over the same horizon: J rel %.2e; relmax W %.2e H %.2e' % (
         abs(Jp - Jr) / Jr, relmax(Wp, W), relmax(Hp, H)))
-    assert abs(Jg - Jr) / Jr < 5e-8 and abs(Jp - Jr) / Jr < 5e-8
+    assert abs(Jg - Jr) / Jr < 1e-7
     assert relmax(model.W, W) < 1e-6 and relmax(model.H, H) < 1e-6 and relmax(model.lag_val, Th) < 1e-6
     assert len(cg_ref) == iters and cg_gpu == cg_ref
     # the fp32 runs against this fp64 trajectory (printed only: the noise floor of the truncated fp32 CG, not an implementation error)
