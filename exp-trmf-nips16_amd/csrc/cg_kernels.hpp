@@ -199,6 +199,8 @@ struct ArVecs {
     const real *hd_in;    // CG_STEP: H d of the previous iteration
     real *s;              // CG_STEP: the step (own rows, in place)
     real *d_out, *r_out;  // CG_STEP: new direction / residual
+    unsigned int *note;   // CG_STEP: pinned host word the deciding workgroup reports (solve, step, stopped) to, or null (xsolve)
+    unsigned int note_seq;
 };
 template <int MODE>
 __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *__restrict__ st, ArVecs a, int np, int it, int last,
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(kArThreads) void ar_tile_kernel(XParams p, XState *
             st->rho_hist[it] = rho_d;
             if (stopped) { st->stop_it = it; st->r_parity = it & 1; }
             else st->cg_iter = it + 1;
+            if (a.note) __hip_atomic_store(a.note, (a.note_seq << 8) | ((unsigned int)it << 1) | (stopped ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     // (1) operand rows -> LDS (zeros outside [0, T)); CG step: s, r, d of the own rows go out

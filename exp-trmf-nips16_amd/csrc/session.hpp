@@ -18,6 +18,7 @@ struct TrmfSessionImpl : SessionXPhase {
         // nothing of this session may still be running when its buffers go back to the pool and its stream to the cache
         if (stream) (void)hipStreamSynchronize(stream);
         if (side) (void)hipStreamSynchronize(side);
+        if (aux_theta) (void)hipStreamSynchronize(aux_theta);
         for (auto &e : events) {
             hipEvent_t all[] = {e.f0, e.fk0, e.fk1, e.f1, e.xg1, e.x1, e.lv1};
             for (hipEvent_t ev : all) if (ev) (void)hipEventDestroy(ev);
@@ -26,6 +27,9 @@ struct TrmfSessionImpl : SessionXPhase {
         release_p2p();
         for (hipEvent_t ev : {ov_b, ov_c[0], ov_c[1], ov_c[2], ov_c[3], emu_ready, emu_end}) if (ev) (void)hipEventDestroy(ev);
         if (side) (void)hipStreamDestroy(side);
+        for (hipEvent_t ev : {theta_fork, theta_done}) if (ev) (void)hipEventDestroy(ev);
+        if (cg_note) (void)hipHostFree(cg_note);
+        StreamCache::release(aux_theta);
         StreamCache::release(stream);
     }
 
@@ -594,6 +598,7 @@ struct TrmfSessionImpl : SessionXPhase {
             TRMF_HIP_CHECK(hipEventRecord(ev.f1, stream));
             if (!doX) TRMF_HIP_CHECK(hipEventRecord(ev.xg1, stream));
             if (doX) {
+                if (join_theta()) return kFail;              // the X-solve reads Theta (and writes W, which the Theta-solve reads)
                 xg1_event = ev.xg1;
                 const int xrc = xsolve(device_log ? &L->x : nullptr, device_log ? &L->normF : nullptr);
                 xg1_event = nullptr;
@@ -618,13 +623,25 @@ struct TrmfSessionImpl : SessionXPhase {
                     log_norm(theta.p, (size_t)nlag * k, &L->normLV);
                     fprintf(stderr, ">> iter %d LV(%d %d) %g\n", iter1, nlag, k, host_double(&L->normLV));
                 }
-                if (theta_solve()) return kFail;
+                // not the last iteration of this call, nothing reads Theta in stream order, long enough to pay: under the next F-solve
+                const bool under_f = nlag > 0 && it + 1 < iters && overlap_ok();
+                if (under_f) {
+                    if (join_theta()) return kFail;
+                    TRMF_HIP_CHECK(hipEventRecord(theta_fork, stream));
+                    TRMF_HIP_CHECK(hipStreamWaitEvent(aux_theta, theta_fork, 0));
+                    if (theta_solve(aux_theta)) return kFail;
+                    TRMF_HIP_CHECK(hipEventRecord(ev.lv1, aux_theta));
+                    TRMF_HIP_CHECK(hipEventRecord(theta_done, aux_theta));
+                    theta_pending = true;
+                    continue;
+                }
+                if (join_theta() || theta_solve(stream)) return kFail;
                 if (log_norms || verbose) log_norm(theta.p, (size_t)nlag * k, &L->normLV);
                 if (verbose) fprintf(stderr, ">> iter %d LV %g\n", iter1, host_double(&L->normLV));
             }
             TRMF_HIP_CHECK(hipEventRecord(ev.lv1, stream));
         }
-        return 0;
+        return join_theta();
     }
     int take_snapshot() {
         const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;

@@ -203,10 +203,10 @@ struct SessionFPhase : SessionTransport {
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }
-    template <int NT_> void launch_small_gram(const real *A, int rows, int nb) {
+    template <int NT_> void launch_small_gram(const real *A, int rows, int nb, hipStream_t stream) {
         hipLaunchKernelGGL((small_gram_mfma_kernel<NT_>), dim3(nb), dim3(256), 0, stream, A, rows, k, sgram_part.p);
     }
-    int small_gram(const real *A, int rows, real lambda, real *GS) {
+    int small_gram(const real *A, int rows, real lambda, real *GS, hipStream_t stream) {
         if (generic) {
             hipLaunchKernelGGL(small_gram_generic_kernel, dim3(k), dim3(256), 0, stream, A, rows, k, KP, NT, lambda, GS);
             return 0;
@@ -214,10 +214,10 @@ struct SessionFPhase : SessionTransport {
         // one partial per wavefront (4 per workgroup), at least 64 rows each, kSmallGramBlocks slots in all
         const int nb = std::max(1, std::min(kSmallGramBlocks / 4, rows / 256));
         switch (NT) {
-            case 1: launch_small_gram<1>(A, rows, nb); break;
-            case 2: launch_small_gram<2>(A, rows, nb); break;
-            case 3: launch_small_gram<3>(A, rows, nb); break;
-            default: launch_small_gram<4>(A, rows, nb); break;
+            case 1: launch_small_gram<1>(A, rows, nb, stream); break;
+            case 2: launch_small_gram<2>(A, rows, nb, stream); break;
+            case 3: launch_small_gram<3>(A, rows, nb, stream); break;
+            default: launch_small_gram<4>(A, rows, nb, stream); break;
         }
         hipLaunchKernelGGL(small_gram_reduce_kernel, dim3((k * k + 3) / 4), dim3(256), 0, stream, sgram_part.p, nb * 4, k, lambda, GS);
         return 0;
@@ -225,8 +225,11 @@ struct SessionFPhase : SessionTransport {
     int fsolve_full(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
         TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        // (W^T W + lambda I and its factor do not depend on Y^T W, but running them beside it on a second stream was measured and is
+        // not faster: the fork / join events cost more than the ~60 us chain they would hide; profiles/r05_streams.txt)
+        hipStream_t gs = stream;
         if (y_times_factor(true, W.p, Bf.p, dense ? 0u : rb, dense ? (uint32_t)n : re)) return kFail;   // Y^T W
-        small_gram(W.p, T, (real)lambdaI, GSf.p);                                                       // W^T W + lambda I
+        small_gram(W.p, T, (real)lambdaI, GSf.p, gs);                                                   // W^T W + lambda I
         if (re > rb && generic) {
             hipLaunchKernelGGL(chol_generic_kernel, dim3(1), dim3(256), 0, stream, GSf.p, Uf.p, k);
             const int nrows = (int)(re - rb);
@@ -234,12 +237,12 @@ struct SessionFPhase : SessionTransport {
                                H.p + (size_t)rb * KP, nrows, k, KP, NT);
         } else if (re > rb) {
             const size_t ulds = (size_t)k * k * sizeof(real);          // <= 32 KB
-            if (test_env("TRMF_CHOL_WORKGROUP")) hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, stream, GSf.p, Uf.p, k);
+            if (test_env("TRMF_CHOL_WORKGROUP")) hipLaunchKernelGGL(chol_shared_kernel, dim3(1), dim3(256), ulds, gs, GSf.p, Uf.p, k);
             else switch (NT) {
-                case 1: hipLaunchKernelGGL(chol_wave_kernel<1>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
-                case 2: hipLaunchKernelGGL(chol_wave_kernel<2>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
-                case 3: hipLaunchKernelGGL(chol_wave_kernel<3>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
-                default: hipLaunchKernelGGL(chol_wave_kernel<4>, dim3(1), dim3(64), 0, stream, GSf.p, Uf.p, k); break;
+                case 1: hipLaunchKernelGGL(chol_wave_kernel<1>, dim3(1), dim3(64), 0, gs, GSf.p, Uf.p, k); break;
+                case 2: hipLaunchKernelGGL(chol_wave_kernel<2>, dim3(1), dim3(64), 0, gs, GSf.p, Uf.p, k); break;
+                case 3: hipLaunchKernelGGL(chol_wave_kernel<3>, dim3(1), dim3(64), 0, gs, GSf.p, Uf.p, k); break;
+                default: hipLaunchKernelGGL(chol_wave_kernel<4>, dim3(1), dim3(64), 0, gs, GSf.p, Uf.p, k); break;
             }
             const int nrows = (int)(re - rb), nblk = std::max(1, std::min(2048, (nrows + 3) / 4));
             hipLaunchKernelGGL(solve_rows_kernel, dim3(nblk), dim3(256), ulds, stream, Uf.p, Bf.p + (size_t)rb * KP,

@@ -199,6 +199,52 @@ struct SessionState {
     hipEvent_t ov_b = nullptr, ov_c[kMaxChunks] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<uint64_t> fcut;               // (world x (chunks + 1)) rows: chunk c of rank r = [fcut[r*(C+1)+c], fcut[r*(C+1)+c+1])
     int fchunks = 0;
+    // ---- the Theta-solve on a second stream (round 5) -------------------------------------------------------------------
+    // The reference's loop is F-solve, X-solve, Theta-solve in sequence (trmf.cpp:647-693), but the data flow is looser: the
+    // Theta-solve of iteration t reads W only and its result is first read by the X-solve of iteration t + 1, so it can run on a
+    // stream of its own underneath the F-solve of iteration t + 1 (which reads W and writes H).  Same kernels, same operands: the
+    // iterates do not change.  The solver stream waits for it before the next X-solve, and run() never returns with work
+    // outstanding there.  A fork + join through events costs ~15-20 us on this platform (profiles/r05_streams.txt), so only a
+    // LONG Theta-solve is moved: the paper scripts' shape (48 lags, 0.25 ms of 1 ms per iteration, +10 %), not config 3 (28 us,
+    // measured: no gain) -- theta_overlap_pays().  Off under verbose / log_norms (their records are written in stream order) and
+    // with TRMF_TEST + TRMF_NO_OVERLAP (A/B measurements, the bit-identity test).
+    hipStream_t aux_theta = nullptr;
+    hipEvent_t theta_fork = nullptr, theta_done = nullptr;
+    bool theta_pending = false;
+    // lagged inner products: k T |L|^2 / 2 multiply-adds in a latency-bound kernel; 1e8 (config 3) = 28 us, 3.6e9 (paper shape) = 250 us
+    bool theta_overlap_pays() const { return (double)k * (double)T * (double)nlag * (double)nlag >= (test_env("TRMF_OVERLAP_ALWAYS") ? 0.0 : 1e9); }
+    bool overlap_ok() { return !verbose && !log_norms && !test_env("TRMF_NO_OVERLAP") && theta_overlap_pays() && ensure_aux() == 0; }
+    int ensure_aux() {
+        if (aux_theta) return 0;
+        if (StreamCache::acquire(&aux_theta)) return kFail;
+        for (hipEvent_t *e : {&theta_fork, &theta_done})
+            if (!*e) TRMF_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+        return 0;
+    }
+    int join_theta() {
+        if (!theta_pending) return 0;
+        theta_pending = false;
+        TRMF_HIP_CHECK(hipStreamWaitEvent(stream, theta_done, 0));
+        return 0;
+    }
+    // ---- the unfused CG follows its own stop (round 5) ------------------------------------------------------------------
+    // The launch-per-step CG enqueues every step up to the cap because the host cannot know where the CG stops; the steps after
+    // the stop return at once but still cost a dispatch each (2 x ~4.6 us x 13..15 unused steps = 0.12 ms of a 0.7 ms X phase at
+    // the paper scripts' shape).  The deciding launch now also writes (solve sequence, step, stopped) into one word of pinned host
+    // memory; the host stays kCgLook steps ahead of the device and stops enqueuing when it sees the stop: at most kCgLook no-op
+    // steps, the device's queue never runs dry, no stream synchronisation.
+    static constexpr int kCgLook = 2;
+    unsigned int *cg_note = nullptr;          // pinned, mapped: (seq << 8) | (step << 1) | stopped
+    unsigned int cg_seq = 0;
+    bool cg_note_failed = false;
+    int ensure_cg_note() {
+        if (cg_note || cg_note_failed) return cg_note ? 0 : kFail;
+        void *p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); cg_note_failed = true; return kFail; }
+        cg_note = (unsigned int *)p;
+        *cg_note = 0;
+        return 0;
+    }
     // ---- the X-solve as ONE persistent kernel (cg_persist.hpp) ---------------------------------------------------------------
     // One rank per GPU and the GPU to itself (world == 1): every tile's workgroup stays resident for the whole solve.  Needs all
     // workgroups co-resident (checked against the occupancy the runtime reports) and the LDS of the resident

@@ -162,7 +162,7 @@ struct SessionXPhase : SessionFPhase {
         const uint32_t rb = (uint32_t)xbounds[comm->rank], re = (uint32_t)xbounds[comm->rank + 1];
         if (y_times_factor(false, H.p, Bv.p, dense ? 0u : rb, dense ? (uint32_t)T : re)) return kFail;  // Y H
         if (!dense && gather_rows(Bv.p, xbounds, (size_t)KP * sizeof(real))) return kFail;
-        small_gram(H.p, n, real(0), GSx.p);                                                             // H^T H
+        small_gram(H.p, n, real(0), GSx.p, stream);                                                     // H^T H
         return 0;
     }
 
@@ -595,10 +595,31 @@ struct SessionXPhase : SessionFPhase {
         if (hv(av, 0, 0, 0, hbuf[0], 1)) return kFail;                   // H d0 and its three dot products
         const bool follow_u = uts && !p2p_use;                            // peer to peer: everything is enqueued at once, as on one GPU
         int upto = follow_u ? std::min(maxcg, std::max(1, cg_pred)) : maxcg;
+        // one rank: stay kCgLook steps ahead of the device and stop enqueuing once the CG has stopped (session_state.hpp, cg_note)
+        const bool follow_note = comm->world == 1 && maxcg > kCgLook + 1 && maxcg < 128 && !test_env("TRMF_NO_CG_FOLLOW") && ensure_cg_note() == 0;
+        const unsigned int seq = follow_note ? (++cg_seq & 0xffffffu) : 0u;
+        bool note_live = follow_note;
         for (int it = 1; it <= maxcg; it++) {                            // launch `maxcg` only closes the last iteration
             av.v = dbuf[(it - 1) & 1]; av.r_in = rbuf[(it - 1) & 1]; av.hd_in = hbuf[(it - 1) & 1];
             av.s = s.p; av.d_out = dbuf[it & 1]; av.r_out = rbuf[it & 1];
+            av.note = follow_note ? cg_note : nullptr; av.note_seq = seq;
             if (hv(av, it, it == maxcg ? 1 : 0, 0, hbuf[it & 1], 1)) return kFail;
+            if (note_live && it < maxcg && it > kCgLook) {
+                // wait until step it - kCgLook has been decided; the device is then still kCgLook steps (>= 100 us of work) behind the queue's end
+                const unsigned int need = (unsigned int)(it - kCgLook);
+                const double t_wait = now_s();
+                bool stopped = false;
+                for (unsigned int spins = 0;; spins++) {
+                    const unsigned int v = __atomic_load_n(cg_note, __ATOMIC_ACQUIRE);
+                    if ((v >> 8) == seq) {
+                        if (v & 1u) { stopped = true; break; }
+                        if (((v >> 1) & 0x7fu) >= need) break;
+                    }
+                    if ((spins & 1023u) == 1023u && now_s() - t_wait > 2.0) { note_live = false; break; }   // a stuck device is the synchronisation's problem, not this loop's
+                    __builtin_ia32_pause();
+                }
+                if (stopped) break;
+            }
             if (!follow_u) continue;
             if (it == upto && it < maxcg) {                              // time-sharded: follow the stop (identical on every rank)
                 int stop = kCgRunning;
@@ -624,7 +645,7 @@ struct SessionXPhase : SessionFPhase {
     // ---- Theta solve (trmf.cpp:677-689 -> 455-484) ------------------------------------------------------
     size_t theta_gram_lds() const { return theta_gram_lds_bytes(midx); }
     size_t theta_solve_lds() const { return (size_t)(nlag * nlag + nlag) * sizeof(real); }
-    int theta_solve() {
+    int theta_solve(hipStream_t stream) {
         if (nlag == 0) return 0;
         const int nchunk = std::max(1, (T - midx + kThetaChunk - 1) / kThetaChunk);
         const int npairs = nlag * (nlag + 1) / 2 + nlag;

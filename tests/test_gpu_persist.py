@@ -84,3 +84,48 @@ def test_persistent_kernel_early_stop_and_iteration_cap(monkeypatch):
         cg = [x['cg_iter'] for x in sa]
         assert cg == [x['cg_iter'] for x in sb]
         assert max(cg) == 20 and min(cg) < 20, cg
+
+
+def _run_quiet(p, m0, dtype, iters, missing, monkeypatch, env):
+    """log_norms off (the mode c_trmf_train and bench.py run in): the Theta-solve may move to its own stream."""
+    from trmf import session, synth
+    for key in ('TRMF_NO_OVERLAP', 'TRMF_OVERLAP_ALWAYS', 'TRMF_NO_CG_FOLLOW'):
+        monkeypatch.delenv(key, raising=False)
+    for key, val in env.items():
+        monkeypatch.setenv(key, val)
+    model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
+    with session.Session(p['Y'].astype(dtype), model, missing=missing, log_norms=False, **synth.HYPER) as s:
+        # two calls: the last iteration of a call never leaves a Theta-solve outstanding, the first iterations do
+        s.run(iters - 2); s.run(2); st = s.stats(iters); s.download(); desc = s.describe()
+    return model, st, desc
+
+
+@pytest.mark.parametrize('case', ['sparse_fused', 'sparse_long_reach', 'dense_long_reach'])
+@pytest.mark.parametrize('dtype', [np.float32, np.float64])
+def test_theta_on_its_own_stream_and_followed_stop_change_nothing(case, dtype, monkeypatch):
+    """Round 5: the Theta-solve of iteration t under the F-solve of iteration t + 1 (its own stream, session_state.hpp) and the
+    unfused CG that stops enqueuing once the device reports the stop (cg_note) are scheduling changes: same kernels, same operands,
+    so factors, CG counts and the TRON numbers must be bit-identical with both switched off."""
+    from trmf import synth
+    if case == 'sparse_fused':
+        p = synth.sparse_problem(n=900, T=400, k=12, nlag=4, density=0.06, dtype=np.float64, seed=11)
+        missing = True
+    elif case == 'sparse_long_reach':                      # lag reach 191: the unfused two-kernel CG step
+        p = synth.sparse_problem(n=500, T=1500, k=8, nlag=4, density=0.05, dtype=np.float64, seed=12)
+        p['lag_set'] = np.array([1, 2, 24, 191], dtype=np.uint32)
+        missing = True
+    else:                                                  # the paper scripts' form: dense Y, missing = 0, long reach
+        p = synth.dense_problem(60, 1200, 6, [1, 2, 24, 168, 191], dtype=np.float64, seed=13)
+        missing = False
+    k = 12 if case == 'sparse_fused' else 8 if case == 'sparse_long_reach' else 6
+    m0 = synth.initial_model(p['Y'], p['lag_set'], k, seed=7)
+    iters = 6
+    a, sa, da = _run_quiet(p, m0, dtype, iters, missing, monkeypatch, {'TRMF_OVERLAP_ALWAYS': '1'})
+    b, sb, db = _run_quiet(p, m0, dtype, iters, missing, monkeypatch, {'TRMF_NO_OVERLAP': '1', 'TRMF_NO_CG_FOLLOW': '1'})
+    if case != 'sparse_fused':
+        assert 'unfused' in da, da
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H) and np.array_equal(a.lag_val, b.lag_val)
+    for x, y in zip(sa, sb):
+        for key in ('f', 'fnew', 'actred', 'prered', 'gnorm', 'cg_rnorm', 'cg_iter', 'accepted', 'delta'):
+            assert x[key] == y[key], (key, x[key], y[key])
+    assert min(x['cg_iter'] for x in sa) < 20            # the stop was there to be followed
