@@ -64,23 +64,33 @@ __device__ __forceinline__ double wave_butterfly_sum(double v) {
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
     return v;
 }
+// NW = wavefronts of the workgroup: 4 (256 threads, every kernel but the wide tiles) or 8 (512 threads: the wide tiles of
+// cg_persist_kernel / hv_tile_kernel / cg_close_kernel); wave sums combined pairwise in index order
+template <int NW>
+__device__ __forceinline__ double wave_sums_fixed(const double *w) {
+    static_assert(NW == 4 || NW == 8, "256 or 512 threads");
+    if constexpr (NW == 4) return (w[0] + w[1]) + (w[2] + w[3]);
+    else return ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+}
+template <int NW = 4>
 __device__ __forceinline__ double block_allsum(double v, double *smem /* >= 16 doubles */) {
     v = wave_butterfly_sum(v);
     if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = v;
     __syncthreads();
-    const double r = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+    const double r = wave_sums_fixed<NW>(smem);
     __syncthreads();
     return r;
 }
 // three sums sharing the barriers
-__device__ __forceinline__ void block_allsum3(double &a, double &b, double &c, double *smem) {
+template <int NW = 4>
+__device__ __forceinline__ void block_allsum3(double &a, double &b, double &c, double *smem /* >= 24 doubles */) {
     a = wave_butterfly_sum(a); b = wave_butterfly_sum(b); c = wave_butterfly_sum(c);
     const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { smem[w] = a; smem[4 + w] = b; smem[8 + w] = c; }
+    if ((threadIdx.x & 63) == 0) { smem[w] = a; smem[NW + w] = b; smem[2 * NW + w] = c; }
     __syncthreads();
-    a = (smem[0] + smem[1]) + (smem[2] + smem[3]);
-    b = (smem[4] + smem[5]) + (smem[6] + smem[7]);
-    c = (smem[8] + smem[9]) + (smem[10] + smem[11]);
+    a = wave_sums_fixed<NW>(smem);
+    b = wave_sums_fixed<NW>(smem + NW);
+    c = wave_sums_fixed<NW>(smem + 2 * NW);
     __syncthreads();
 }
 // Sum of a partial array written by a producer kernel with `np` blocks; identical in every block.
@@ -627,7 +637,7 @@ constexpr int kHvGramPad = 4;                    // elements allocated past the 
 // slice, KQ loads, has to stay within ~160 of the 256 registers)
 __host__ __device__ constexpr int hv_vec(int KQ) { return (KQ <= 40 ? 16 : 8) / (int)sizeof(real); }
 __host__ __device__ constexpr int hv_kq(int k) { return (k + 7) / 8 * 8; }
-__host__ __device__ inline int hv_tile_rows(int k) { const int vec = hv_vec(hv_kq(k)); return 256 / ((k + vec - 1) / vec); }
+__host__ __device__ inline int hv_tile_rows(int k, int threads = 256) { const int vec = hv_vec(hv_kq(k)); return threads / ((k + vec - 1) / vec); }
 
 // VEC consecutive Gram entries through a raw buffer load: address = wave-uniform descriptor base (the
 // tile's first Gram) + scalar offset (Gram row j) + one 32-bit lane offset -- no per-load vector address.
@@ -866,7 +876,7 @@ __global__ __launch_bounds__(256) void uts_push_kernel(const PeerTable *__restri
 #endif
 
 #if !defined(TRMF_UNIT_BODIES)     // the main translation unit sees the declaration only (kernel_units.hpp)
-template <int MODE, int KQ, bool SHARD>
+template <int MODE, int KQ, bool SHARD, int NTH = 256>
 __global__ void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,
                                                          const uint32_t *__restrict__ lag_set,
@@ -875,8 +885,8 @@ __global__ void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, Til
                                                          const double *__restrict__ rec_in, double *__restrict__ rec_out,
                                                          const PeerTable *__restrict__ pt, int mi, int TI);
 #else
-template <int MODE, int KQ, bool SHARD>
-__global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
+template <int MODE, int KQ, bool SHARD, int NTH>
+__global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,
                                                          const uint32_t *__restrict__ lag_set,
                                                          const real *__restrict__ theta,
@@ -920,7 +930,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     int lagr = 0;
     if (nlag > 0) {
 #pragma unroll
-        for (int m = 0; m < kHvThetaRegs; m++) thr[m] = theta[min(tid + 256 * m, nTh - 1)];
+        for (int m = 0; m < kHvThetaRegs; m++) thr[m] = theta[min(tid + NTH * m, nTh - 1)];
         lagr = (int)lag_set[min(tid, nlag - 1)];
     }
     real tmp = 0, alpha = 0, nalpha = 0;
@@ -929,12 +939,12 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     // operand rows and the Gram slice, and only then reduced -- the whole request stream of the launch is
     // in flight before the first wait.  (More than 512 tiles: read in a loop after the requests instead.)
     constexpr int kEarlyPartials = 2;                       // x 256 threads
-    const bool early = MODE == HV_CG_STEP && np_in <= 256 * kEarlyPartials;
+    const bool early = MODE == HV_CG_STEP && np_in <= NTH * kEarlyPartials;
     double pq[3][kEarlyPartials];
     if (MODE == HV_CG_STEP && early) {
 #pragma unroll
         for (int m = 0; m < kEarlyPartials; m++) {
-            const double *rec = rec_in + rec_index<SHARD>(sh, min(tid + 256 * m, np_in - 1));
+            const double *rec = rec_in + rec_index<SHARD>(sh, min(tid + NTH * m, np_in - 1));
 #pragma unroll
             for (int a3 = 0; a3 < 3; a3++) pq[a3][m] = rec[a3];
         }
@@ -942,12 +952,12 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     if (MODE == HV_CG_FIRST) {
         // f, |g|, tolerances from the gradient launch's partials (rf_tron.h:154-169, 424-439)
         double ar2 = 0, vv = 0, gg = 0, lq = 0;
-        for (int i = tid; i < np_in; i += 256) {
+        for (int i = tid; i < np_in; i += NTH) {
             const double *rec = rec_in + rec_index<SHARD>(sh, i);
             ar2 += rec[0]; vv += rec[1]; gg += rec[2]; lq += rec[3];
         }
-        block_allsum3(ar2, vv, gg, smem);
-        lq = block_allsum(lq, smem);
+        block_allsum3<NTH / 64>(ar2, vv, gg, smem);
+        lq = block_allsum<NTH / 64>(lq, smem);
         const real ggr = (real)gg;                                           // BLAS dot in val_type
         const double gnorm = sqrt((double)ggr);
         const real cgtol = (real)(p.eps_cg * gnorm);                         // rf_tron.h:434
@@ -984,11 +994,11 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     real vr[kHvOperandRegs], rv[kHvOperandRegs], hr[kHvOperandRegs], sr[kHvOperandRegs];
 #pragma unroll
     for (int m = 0; m < kHvOperandRegs; m++) {
-        vr[m] = buffer_load_real(v_rsrc, vbyte0 + 256 * m * sz);
+        vr[m] = buffer_load_real(v_rsrc, vbyte0 + NTH * m * sz);
         if (MODE == HV_CG_STEP) {
-            rv[m] = buffer_load_real(r_rsrc, vbyte0 + 256 * m * sz);
-            hr[m] = buffer_load_real(h_rsrc, vbyte0 + 256 * m * sz);
-            sr[m] = buffer_load_real(s_rsrc, obyte0 + 256 * m * sz);
+            rv[m] = buffer_load_real(r_rsrc, vbyte0 + NTH * m * sz);
+            hr[m] = buffer_load_real(h_rsrc, vbyte0 + NTH * m * sz);
+            sr[m] = buffer_load_real(s_rsrc, obyte0 + NTH * m * sz);
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1034,18 +1044,18 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         };
 #pragma unroll
         for (int m = 0; m < kHvThetaRegs; m++)
-            if (tid + 256 * m < nTh) put(tid + 256 * m, thr[m]);
+            if (tid + NTH * m < nTh) put(tid + NTH * m, thr[m]);
 #pragma nounroll
-        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) put(e, theta[e]);
+        for (int e = tid + NTH * kHvThetaRegs; e < nTh; e += NTH) put(e, theta[e]);
 #pragma nounroll
-        for (int e = tid; e < nlag * (KP - k); e += 256) {                  // pad columns: exact zeros
+        for (int e = tid; e < nlag * (KP - k); e += NTH) {                  // pad columns: exact zeros
             const int l = e / (KP - k), tt = k + (e - l * (KP - k));
             thp[l * KP + colpos(tt, NT_T)] = 0;
             thd[l * KP + tt] = 0;
         }
         if (tid < nlag) lags[tid] = lagr;
 #pragma nounroll
-        for (int e = tid + 256; e < nlag; e += 256) lags[e] = (int)lag_set[e];
+        for (int e = tid + NTH; e < nlag; e += NTH) lags[e] = (int)lag_set[e];
     }
 
     if (MODE == HV_CG_STEP) {
@@ -1053,14 +1063,14 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         if (early) {
 #pragma unroll
             for (int m = 0; m < kEarlyPartials; m++)
-                if (tid + 256 * m < np_in) { dHd += pq[0][m]; rHd += pq[1][m]; HH += pq[2][m]; }
+                if (tid + NTH * m < np_in) { dHd += pq[0][m]; rHd += pq[1][m]; HH += pq[2][m]; }
         } else {
-            for (int i = tid; i < np_in; i += 256) {
+            for (int i = tid; i < np_in; i += NTH) {
                 const double *rec = rec_in + rec_index<SHARD>(sh, i);
                 dHd += rec[0]; rHd += rec[1]; HH += rec[2];
             }
         }
-        block_allsum3(dHd, rHd, HH, smem);
+        block_allsum3<NTH / 64>(dHd, rHd, HH, smem);
         const double rho_prev_d = st->rho_hist[it - 1];
         const real rho_prev = (real)rho_prev_d;
         alpha = rho_prev / (real)dHd;                                        // rf_tron.h:460
@@ -1134,10 +1144,10 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
     };
 #pragma unroll
     for (int m = 0; m < kHvOperandRegs; m++)
-        operand(tid + 256 * m, vr[m], MODE == HV_CG_STEP ? rv[m] : real(0), MODE == HV_CG_STEP ? hr[m] : real(0),
+        operand(tid + NTH * m, vr[m], MODE == HV_CG_STEP ? rv[m] : real(0), MODE == HV_CG_STEP ? hr[m] : real(0),
                 MODE == HV_CG_STEP ? sr[m] : real(0));
 #pragma nounroll
-    for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256) {           // very long halos only
+    for (int e = tid + NTH * kHvOperandRegs; e < nV; e += NTH) {           // very long halos only
         const int vb = vbyte0 + (e - tid) * sz, ob = obyte0 + (e - tid) * sz;
         operand(e, buffer_load_real(v_rsrc, vb), MODE == HV_CG_STEP ? buffer_load_real(r_rsrc, vb) : real(0),
                 MODE == HV_CG_STEP ? buffer_load_real(h_rsrc, vb) : real(0),
@@ -1157,13 +1167,13 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         constexpr int NG = KP / 4;
         const int items = rowsR * NG;
 #pragma nounroll
-        for (int it0 = 0; it0 < items; it0 += 256 * kHvResU) {
+        for (int it0 = 0; it0 < items; it0 += NTH * kHvResU) {
             int vb[kHvResU], pg[kHvResU];
             bool on[kHvResU];
             double res[kHvResU][4];
 #pragma unroll
             for (int u = 0; u < kHvResU; u++) {
-                const int it = it0 + tid + 256 * u;
+                const int it = it0 + tid + NTH * u;
                 const int rr = it / NG, g = it - rr * NG, i = i0 + rr;
                 on[u] = it < items && i >= Hh && i < T;
                 vb[u] = on[u] ? (rr + Hh) * KP + 4 * g : Hh * KP;
@@ -1189,7 +1199,7 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
             }
 #pragma unroll
             for (int u = 0; u < kHvResU; u++) {
-                const int it = it0 + tid + 256 * u;
+                const int it = it0 + tid + NTH * u;
                 const int rr = it / NG, g = it - rr * NG;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -1300,13 +1310,13 @@ __global__ __launch_bounds__(256, 2) void hv_tile_kernel(XParams p, XState *__re
         }
     }
     if (CG) {
-        block_allsum3(dot, rhd, hh, smem);
+        block_allsum3<NTH / 64>(dot, rhd, hh, smem);
         if (threadIdx.x == 0) put_record(0, dot, rhd, hh, 0, false);
         if (p2p) __threadfence_system();
         return;
     }
-    block_allsum3(ar2, vv, dot, smem);
-    if (GRAD) lq = block_allsum(lq, smem);
+    block_allsum3<NTH / 64>(ar2, vv, dot, smem);
+    if (GRAD) lq = block_allsum<NTH / 64>(lq, smem);
     if (threadIdx.x == 0) put_record(0, ar2, vv, dot, lq, GRAD);     // [2]: <g,g> of the gradient launch, <v,Hv> of the plain one
     if (p2p) __threadfence_system();
 }
@@ -1443,8 +1453,8 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
 // s += alpha d, r' = r - alpha Hd (needed only for <s,r'>), w_new = w + s, and the per-tile sums <g,s>, <s,r'>, <s,s>
 // into fields [4..6] of the records of the gradient / plain message; with several ranks also the first / last midx rows of
 // s (edge vector 0).  One workgroup per tile, own rows only; stop_it = 0 (the gradient met the tolerance): s = 0.
-template <bool SHARD>
-__global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *__restrict__ st, TileShard sh, int TI,
+template <bool SHARD, int NTH = 256>
+__global__ __launch_bounds__(NTH) void cg_close_kernel(XParams p, const XState *__restrict__ st, TileShard sh, int TI,
                                                       const double *__restrict__ msg_even, const double *__restrict__ msg_odd,
                                                       const real *__restrict__ d_even, const real *__restrict__ d_odd,
                                                       const real *__restrict__ r_even, const real *__restrict__ r_odd,
@@ -1465,15 +1475,15 @@ __global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *
     real xd[kPer], xh[kPer], xr[kPer], xs[kPer], xg[kPer], xw[kPer];
 #pragma unroll
     for (int m = 0; m < kPer; m++) {
-        const int e = min(e0 + 256 * m, e1 - 1);
+        const int e = min(e0 + NTH * m, e1 - 1);
         xd[m] = dv[e]; xh[m] = hv[e]; xr[m] = rv[e]; xs[m] = s[e]; xg[m] = g[e]; xw[m] = w[e];
     }
     real alpha = 0;
     if (it >= 1) {                                      // uniform: every workgroup (and rank) sees the same stop_it
         const double *msg = par ? msg_odd : msg_even;
         double dHd = 0;
-        for (int i = tid; i < sh.nbt; i += 256) dHd += msg[rec_index<SHARD>(sh, i)];
-        dHd = block_allsum(dHd, smem);
+        for (int i = tid; i < sh.nbt; i += NTH) dHd += msg[rec_index<SHARD>(sh, i)];
+        dHd = block_allsum<NTH / 64>(dHd, smem);
         alpha = (real)st->rho_hist[it - 1] / (real)dHd;                     // rf_tron.h:460
     }
     const bool p2p = SHARD && pt != nullptr;
@@ -1494,9 +1504,9 @@ __global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *
     };
 #pragma unroll
     for (int m = 0; m < kPer; m++)
-        if (e0 + 256 * m < e1) close_elem(e0 + 256 * m, xd[m], xh[m], xr[m], xs[m], xg[m], xw[m]);
-    for (int e = e0 + 256 * kPer; e < e1; e += 256) close_elem(e, dv[e], hv[e], rv[e], s[e], g[e], w[e]);
-    block_allsum3(gs, sr, ss, smem);
+        if (e0 + NTH * m < e1) close_elem(e0 + NTH * m, xd[m], xh[m], xr[m], xs[m], xg[m], xw[m]);
+    for (int e = e0 + NTH * kPer; e < e1; e += NTH) close_elem(e, dv[e], hv[e], rv[e], s[e], g[e], w[e]);
+    block_allsum3<NTH / 64>(gs, sr, ss, smem);
     if (tid == 0) {
         const size_t ri = rec_index<SHARD>(sh, tile) + 4;
         for (int r = 0; r < (p2p ? sh.world : 1); r++) {
@@ -1511,18 +1521,19 @@ __global__ __launch_bounds__(256) void cg_close_kernel(XParams p, const XState *
 // <g,s>, <s,r>, <s,s> (cg_close_kernel) and <s,Hs> (plain launch) sit in the same records; with several ranks a rank
 // commits its own timestamps [row_b, row_e) (the rows of W are all-gathered next).
 #if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
-__global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msgP,
+template <int NTH = 256>
+__global__ __launch_bounds__(NTH) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msgP,
                                                           TileShard sh, int sharded, const real *__restrict__ w_new,
                                                           real *__restrict__ w, XState *__restrict__ log_x,
                                                           double *__restrict__ log_norms) {
     __shared__ double smem[256];
     double gs_d = 0, sr_d = 0, ss_d = 0, sHs = 0;
-    for (int i = threadIdx.x; i < sh.nbt; i += 256) {
+    for (int i = threadIdx.x; i < sh.nbt; i += NTH) {
         const size_t ri = sharded ? rec_index<true>(sh, i) : rec_index<false>(sh, i);
         gs_d += msgP[ri + 4]; sr_d += msgP[ri + 5]; ss_d += msgP[ri + 6]; sHs += msgP[ri + 2];
     }
-    block_allsum3(gs_d, sr_d, ss_d, smem);
-    sHs = block_allsum(sHs, smem);
+    block_allsum3<NTH / 64>(gs_d, sr_d, ss_d, smem);
+    sHs = block_allsum<NTH / 64>(sHs, smem);
     const double gs = (double)(real)gs_d, sr = (double)(real)sr_d;          // BLAS dots in val_type (rf_tron.h:186-187)
     const double snorm = sqrt((double)(real)ss_d);
     const double rho = (double)(real)st->rho_hist[st->cg_iter];
@@ -1533,7 +1544,7 @@ __global__ __launch_bounds__(256) void accept_tile_kernel(XParams p, XState *__r
     const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
     if (accept) {
         const size_t e0 = (size_t)sh.row_b * p.KP, e1 = (size_t)sh.row_e * p.KP;
-        for (size_t e = e0 + (size_t)blockIdx.x * 256 + threadIdx.x; e < e1; e += (size_t)gridDim.x * 256) w[e] = w_new[e];
+        for (size_t e = e0 + (size_t)blockIdx.x * NTH + threadIdx.x; e < e1; e += (size_t)gridDim.x * NTH) w[e] = w_new[e];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {          // fields no block reads in this kernel
         st->fnew = fnew; st->gs = gs; st->sr = sr;

@@ -77,11 +77,12 @@ template <typename R> __device__ __forceinline__ void ll_unpack(const pu4 &w, R 
     else dst[0] = (R)__longlong_as_double((long long)(((unsigned long long)w.z << 32) | (unsigned long long)w.x));
 }
 
-template <int KQ, bool SHARD>
-__global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *__restrict__ st, PersistArgs a) {
+template <int KQ, bool SHARD, int NTH>
+__global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XParams p, XState *__restrict__ st, PersistArgs a) {
     constexpr int kAuxLd = SHARD ? (kSc1 | 1) : kSc1;        // polls: device scope on one GPU, system scope when peers store into the arena
     extern __shared__ __attribute__((aligned(16))) unsigned char hv_smem[];
     __shared__ double smem[256];
+    constexpr int NW = NTH / 64;                             // wavefronts of the workgroup
     __shared__ double keep[8];          // uniform scalars of the solve (f, |g|, ...): parked in LDS, not in registers, between their uses
     __shared__ int s_fail;
     constexpr int VEC = hv_vec(KQ);
@@ -106,8 +107,11 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     double *rs = reinterpret_cast<double *>(hv_smem + 3 * vecb + 2 * ownb);
     double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * RPITCH * sizeof(double) + 15) / 16 * 16));
     real *thp = reinterpret_cast<real *>(thd + (size_t)nlag * KP);
-    int *lags = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
-    double *recs = reinterpret_cast<double *>(hv_smem + (((size_t)(reinterpret_cast<unsigned char *>(lags + nlag) - hv_smem) + 15) / 16 * 16));   // [tiles][4]
+    // the lag set as the two element offsets the phases need (lag * KP into the staged operand, lag * RPITCH into the residual rows),
+    // two spare entries each: a loop over pairs of lags reads the NEXT pair's offsets while it works on the current one
+    int *lagv = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
+    int *lagq = lagv + nlag + 2;
+    double *recs = reinterpret_cast<double *>(hv_smem + (((size_t)(reinterpret_cast<unsigned char *>(lagq + nlag + 2) - hv_smem) + 15) / 16 * 16));   // [tiles][4]
     if (tid == 0) s_fail = 0;
     // an earlier solve of this session ran into a poll bound: the iterates are void until the host has recovered (session.hpp,
     // persist_recover); do not spend another bound per queued solve
@@ -135,18 +139,22 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     // stream -- the staging and the AR phases of the gradient run underneath it
     const size_t vec_bytes = (size_t)T * KP * sizeof(real);
     const int vbyte0 = (i0 - Hh) * KP * sz;
-    real thr[kHvThetaRegs];
+    constexpr int kThRegs = NTH == 256 ? kHvThetaRegs : 2;
+    real thr[kThRegs];
     int lagr = 0;
     if (nlag > 0) {                  // Theta / the lag set first: their staging must not queue behind the Gram stream
 #pragma unroll
-        for (int m = 0; m < kHvThetaRegs; m++) thr[m] = a.theta[min(tid + 256 * m, nTh - 1)];
+        for (int m = 0; m < kThRegs; m++) thr[m] = a.theta[min(tid + NTH * m, nTh - 1)];
         lagr = (int)a.lag_set[min(tid, nlag - 1)];
     }
-    real vr[kHvOperandRegs];
+    // operand elements requested ahead of the Gram stream: nV <= 12 x 256 at every fused shape; the wide tile (more threads, fewer
+    // elements per thread) needs 8, and its fp64 rank-40 instantiation has no register to spare
+    constexpr int kOpRegs = NTH == 256 ? kHvOperandRegs : 8;
+    real vr[kOpRegs];
     {
         const __amdgpu_buffer_rsrc_t v_rsrc = buffer_rsrc(a.W, vec_bytes);
 #pragma unroll
-        for (int m = 0; m < kHvOperandRegs; m++) vr[m] = buffer_load_real(v_rsrc, vbyte0 + (tid + 256 * m) * sz);   // zeros outside [0, T)
+        for (int m = 0; m < kOpRegs; m++) vr[m] = buffer_load_real(v_rsrc, vbyte0 + (tid + NTH * m) * sz);   // zeros outside [0, T)
     }
     __builtin_amdgcn_sched_barrier(0);
     GramVec<VEC> gq[KQ];
@@ -170,22 +178,23 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             thd[l * KP + tt] = p.lambdaAR * (double)th;
         };
 #pragma unroll
-        for (int m = 0; m < kHvThetaRegs; m++)
-            if (tid + 256 * m < nTh) put(tid + 256 * m, thr[m]);
+        for (int m = 0; m < kThRegs; m++)
+            if (tid + NTH * m < nTh) put(tid + NTH * m, thr[m]);
 #pragma nounroll
-        for (int e = tid + 256 * kHvThetaRegs; e < nTh; e += 256) put(e, a.theta[e]);         // many lags x high rank only
+        for (int e = tid + NTH * kThRegs; e < nTh; e += NTH) put(e, a.theta[e]);         // many lags x high rank only
 #pragma nounroll
-        for (int e = tid; e < nlag * (KP - k); e += 256) {
+        for (int e = tid; e < nlag * (KP - k); e += NTH) {
             const int l = e / (KP - k), tt = k + (e - l * (KP - k));
             thp[l * KP + colpos(tt, NT_T)] = 0;
             thd[l * KP + tt] = 0;
         }
-        if (tid < nlag) lags[tid] = lagr;
+        if (tid < nlag) { lagv[tid] = lagr * KP; lagq[tid] = lagr * RPITCH; }
 #pragma nounroll
-        for (int e = tid + 256; e < nlag; e += 256) lags[e] = (int)a.lag_set[e];
+        for (int e = tid + NTH; e < nlag; e += NTH) { const int lg = (int)a.lag_set[e]; lagv[e] = lg * KP; lagq[e] = lg * RPITCH; }
+        if (tid < 2) { lagv[nlag + tid] = 0; lagq[nlag + tid] = 0; }
     }
-    for (int e = tid; e < nV; e += 256) { rst[e] = 0; hst[e] = 0; }
-    for (int e = tid; e < TI * KP; e += 256) { sown[e] = 0; gown[e] = 0; }
+    for (int e = tid; e < nV; e += NTH) { rst[e] = 0; hst[e] = 0; }
+    for (int e = tid; e < TI * KP; e += NTH) { sown[e] = 0; gown[e] = 0; }
 
     // (descriptors of the exchanged vectors: staged element e = vector element (i0 - midx) * KP + e; offsets outside the
     // vector read 0 -- a negative offset wraps to a huge unsigned -- the clipping hv_tile_kernel relies on)
@@ -234,23 +243,27 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     };
     auto collect = [&](int x, int NF, double (&sum)[4], bool halo, real *dst_staged) -> bool {
         const uint32_t tag = a.epoch0 + (uint32_t)x;
-        const int base = (x & 1) * nbt, wave = tid >> 6, lane = tid & 63;
+        // (the record indices of the wave's chunks are otherwise hoisted out of the CG loop and kept for the whole kernel -- the rank-40
+        // instantiations have no register for that; an opaque copy of the thread index keeps them local to the call)
+        int tid_c = tid;
+        asm volatile("" : "+v"(tid_c));
+        const int base = (x & 1) * nbt, wave = tid_c >> 6, lane = tid_c & 63;
         // records: wave w owns the chunks w, w + 4, ... (16 records each; lane = (record of the chunk, 16-byte quarter))
-        constexpr int NCW = kPersistMaxTiles / 16 / 4;          // chunks per wave at most (8): polled in groups of NC
+        constexpr int NCW = kPersistMaxTiles / 16 / NW;          // chunks per wave at most (8): polled in groups of NC
         constexpr int NC = (KQ * VEC * (int)sizeof(real) / 4 >= 160) ? 2 : 3;   // (the 160-register Gram slices leave room for two requests in flight only)
         const int q = lane & 3, r = lane >> 2;
         uint32_t cpend = 0;                                      // wave-uniform: bit j = chunk wave + 4 j still incomplete
 #pragma unroll
-        for (int j = 0; j < NCW; j++) if (wave + 4 * j < nchunks) cpend |= 1u << j;
+        for (int j = 0; j < NCW; j++) if (wave + NW * j < nchunks) cpend |= 1u << j;
         // halo rows: unit u = tid + 256 m of the 2 * midx rows on either side of the tile; rows outside [0, T) are zeros
         constexpr int NU = 3;
         const int units = halo ? 2 * own0 / PER : 0;
         const __amdgpu_buffer_rsrc_t rs_ = buffer_rsrc(reinterpret_cast<const unsigned char *>(a.hll) + (size_t)(x & 1) * hll_elems * EB, hll_elems * EB);
-        for (int u0 = 0; u0 < units || cpend; u0 += 256 * NU) {           // (more than 768 halo units: further rounds, records done by then)
+        for (int u0 = 0; u0 < units || cpend; u0 += NTH * NU) {           // (more than 768 halo units: further rounds, records done by then)
             int es[NU]; bool need[NU];
 #pragma unroll
             for (int m = 0; m < NU; m++) {
-                const int u = u0 + tid + 256 * m, e = u * PER;
+                const int u = u0 + tid + NTH * m, e = u * PER;
                 es[m] = e < own0 ? e : e + TI * KP;
                 const int i = i0 - Hh + es[m] / KP;
                 need[m] = u < units && i >= 0 && i < T;
@@ -272,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
 #pragma unroll
                     for (int j = 0; j < NC; j++)
                         if ((cpend >> (g0 + j)) & 1u)
-                            wc[j] = __builtin_amdgcn_raw_buffer_load_b128(ll_rsrc, (base + min(16 * (wave + 4 * (g0 + j)) + r, nbt - 1)) * 64 + q * 16, 0, kAuxLd);
+                            wc[j] = __builtin_amdgcn_raw_buffer_load_b128(ll_rsrc, (base + min(16 * (wave + NW * (g0 + j)) + r, nbt - 1)) * 64 + q * 16, 0, kAuxLd);
                     if (g0 == 0) {
 #pragma unroll
                         for (int m = 0; m < NU; m++)
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
 #pragma unroll
                     for (int j = 0; j < NC; j++) {
                         if (!((cpend >> (g0 + j)) & 1u)) continue;                 // wave-uniform
-                        const int rec = 16 * (wave + 4 * (g0 + j)) + r;
+                        const int rec = 16 * (wave + NW * (g0 + j)) + r;
                         const bool valid = rec < nbt, ok = !valid || (wc[j].y == tag && wc[j].w == tag);
                         if (valid && ok) recs[rec * 4 + q] = __longlong_as_double((long long)(((unsigned long long)wc[j].z << 32) | (unsigned long long)wc[j].x));
                         if (__all(ok)) cpend &= ~(1u << (g0 + j));
@@ -302,13 +315,13 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         }
         __syncthreads();
         double acc[4] = {0, 0, 0, 0};
-        for (int i = tid; i < nbt; i += 256) {
+        for (int i = tid; i < nbt; i += NTH) {
             const VecOf<double, 4> v = *reinterpret_cast<const VecOf<double, 4> *>(recs + i * 4);
 #pragma unroll
             for (int q = 0; q < 4; q++) acc[q] += v.v[q];
         }
-        block_allsum3(acc[0], acc[1], acc[2], smem);
-        if (NF > 3) acc[3] = block_allsum(acc[3], smem);
+        block_allsum3<NW>(acc[0], acc[1], acc[2], smem);
+        if (NF > 3) acc[3] = block_allsum<NW>(acc[3], smem);
         sum[0] = acc[0]; sum[1] = acc[1]; sum[2] = acc[2]; sum[3] = acc[3];
         if (s_fail) {                                        // read after the barriers of the block sums: uniform in the workgroup
             if (tid == 0) {
@@ -327,7 +340,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         const __amdgpu_buffer_rsrc_t rs_ = buffer_rsrc(reinterpret_cast<const unsigned char *>(a.hll) + ((size_t)(x & 1) * hll_elems + (size_t)i0 * KP) * EB,
                                                        (size_t)own_n * EB);
         constexpr int kAuxSt = SHARD ? (kSc1 | 1) : kSc1;
-        for (int u = tid; u < own_n / PER; u += 256) {
+        for (int u = tid; u < own_n / PER; u += NTH) {
             __builtin_amdgcn_raw_buffer_store_b128(ll_pack<real>(src_own, u, tag), rs_, u * 16, 0, kAuxSt);
         }
         if constexpr (SHARD) {
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             if (lo || hi) {
                 const __amdgpu_buffer_rsrc_t rlo = buffer_rsrc(reinterpret_cast<const unsigned char *>(lo ? a.peer_hll[a.sh.rank - 1] : a.hll) + off, (size_t)own_n * EB);
                 const __amdgpu_buffer_rsrc_t rhi = buffer_rsrc(reinterpret_cast<const unsigned char *>(hi ? a.peer_hll[a.sh.rank + 1] : a.hll) + off, (size_t)own_n * EB);
-                for (int u = tid; u < own_n / PER; u += 256) {
+                for (int u = tid; u < own_n / PER; u += NTH) {
                     const int i = i0 + (u * PER) / KP;
                     const pu4 w = ll_pack<real>(src_own, u, tag);
                     if (lo && i < a.sh.row_b + Hh) __builtin_amdgcn_raw_buffer_store_b128(w, rlo, u * 16, 0, kAuxSt);
@@ -358,13 +371,13 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         const int items = rowsR * NG;
         const int tid = opaque((int)threadIdx.x);
 #pragma nounroll
-        for (int it0 = 0; it0 < items; it0 += 256 * kResU) {
+        for (int it0 = 0; it0 < items; it0 += NTH * kResU) {
             int vb[kResU], pg[kResU];
             bool on[kResU];
             double res[kResU][4];
 #pragma unroll
             for (int u = 0; u < kResU; u++) {
-                const int it = it0 + tid + 256 * u;
+                const int it = it0 + tid + NTH * u;
                 const int rr = it / NG, g = it - rr * NG, i = i0 + rr;
                 on[u] = it < items && i >= Hh && i < T;
                 vb[u] = on[u] ? (rr + Hh) * KP + 4 * g : Hh * KP;
@@ -373,24 +386,44 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
 #pragma unroll
                 for (int c = 0; c < 4; c++) res[u][c] = (double)x4.v[c];
             }
-#pragma unroll 2
-            for (int l = 0; l < nlag; l++) {
-                const int back = lags[l] * KP;
-                const real *thl = thp + l * KP;
+            // Two lags per trip, lags in order (the reference's summation order, trmf.cpp:110-113).  The operand row of a lag sits at an
+            // offset that is itself read from LDS: as a plain loop every lag cost TWO dependent LDS round trips (offset, then operand;
+            // seen in the ISA: ds_read2_b32 -> s_waitcnt -> v_mul_lo -> ds_read_b128 -> s_waitcnt).  The offsets are now stored
+            // pre-multiplied and the next pair's are requested behind this pair's operands: one round trip per pair.
+            static_assert(kResU == 1, "one work item per thread in the persistent kernel");
+            int bn0 = lagv[0], bn1 = lagv[1];
+            int l = 0;
+#pragma nounroll
+            for (; l + 1 < nlag; l += 2) {
+                const int b0 = bn0, b1 = bn1;
+                const Quad<real> tha = *reinterpret_cast<const Quad<real> *>(thp + l * KP + pg[0]);
+                const Quad<real> thb = *reinterpret_cast<const Quad<real> *>(thp + (l + 1) * KP + pg[0]);
+                const Quad<real> xa = *reinterpret_cast<const Quad<real> *>(vs + vb[0] - b0);
+                const Quad<real> xb = *reinterpret_cast<const Quad<real> *>(vs + vb[0] - b1);
+                bn0 = lagv[l + 2]; bn1 = lagv[l + 3];
 #pragma unroll
-                for (int u = 0; u < kResU; u++) {
-                    const Quad<real> th4 = *reinterpret_cast<const Quad<real> *>(thl + pg[u]);
-                    const Quad<real> x4 = *reinterpret_cast<const Quad<real> *>(vs + vb[u] - back);
+                for (int c = 0; c < 4; c++) {
+                    const real prod = tha.v[c] * xa.v[c];
+                    res[0][c] -= (double)prod;
+                }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const real prod = th4.v[c] * x4.v[c];
-                        res[u][c] -= (double)prod;
-                    }
+                for (int c = 0; c < 4; c++) {
+                    const real prod = thb.v[c] * xb.v[c];
+                    res[0][c] -= (double)prod;
+                }
+            }
+            if (l < nlag) {
+                const Quad<real> tha = *reinterpret_cast<const Quad<real> *>(thp + l * KP + pg[0]);
+                const Quad<real> xa = *reinterpret_cast<const Quad<real> *>(vs + vb[0] - bn0);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const real prod = tha.v[c] * xa.v[c];
+                    res[0][c] -= (double)prod;
                 }
             }
 #pragma unroll
             for (int u = 0; u < kResU; u++) {
-                const int it = it0 + tid + 256 * u;
+                const int it = it0 + tid + NTH * u;
                 const int rr = it / NG, g = it - rr * NG;
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
@@ -426,12 +459,28 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
 #pragma unroll
                 for (int c = 0; c < VEC; c++) od[c] += p.lambdaAR * r0.v[c];
             }
-#pragma unroll 2
-            for (int l = 0; l < nlag; l++) {
-                const VecOf<double, VEC> r4 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + (rr + lags[l]) * RPITCH + t0);
-                const VecOf<double, VEC> t4 = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
+            // (lags in pairs, the next pair's residual-row offsets requested ahead: see ar_residuals)
+            const double *rrow = rs + rr * RPITCH + t0;
+            int qn0 = lagq[0], qn1 = lagq[1];
+            int l = 0;
+#pragma nounroll
+            for (; l + 1 < nlag; l += 2) {
+                const int q0 = qn0, q1 = qn1;
+                const VecOf<double, VEC> ra = *reinterpret_cast<const VecOf<double, VEC> *>(rrow + q0);
+                const VecOf<double, VEC> ta = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
+                const VecOf<double, VEC> rb = *reinterpret_cast<const VecOf<double, VEC> *>(rrow + q1);
+                const VecOf<double, VEC> tb = *reinterpret_cast<const VecOf<double, VEC> *>(thd + (l + 1) * KP + t0);
+                qn0 = lagq[l + 2]; qn1 = lagq[l + 3];
 #pragma unroll
-                for (int c = 0; c < VEC; c++) od[c] -= r4.v[c] * t4.v[c];
+                for (int c = 0; c < VEC; c++) od[c] -= ra.v[c] * ta.v[c];
+#pragma unroll
+                for (int c = 0; c < VEC; c++) od[c] -= rb.v[c] * tb.v[c];
+            }
+            if (l < nlag) {
+                const VecOf<double, VEC> ra = *reinterpret_cast<const VecOf<double, VEC> *>(rrow + qn0);
+                const VecOf<double, VEC> ta = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
+#pragma unroll
+                for (int c = 0; c < VEC; c++) od[c] -= ra.v[c] * ta.v[c];
             }
         }
         double acc[VEC];
@@ -483,10 +532,10 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             if (e < nV) vs[e] = x;
         };
 #pragma unroll
-        for (int m = 0; m < kHvOperandRegs; m++) stage_w(tid + 256 * m, vr[m]);
+        for (int m = 0; m < kOpRegs; m++) stage_w(tid + NTH * m, vr[m]);
         const __amdgpu_buffer_rsrc_t v_rsrc = buffer_rsrc(a.W, vec_bytes);
 #pragma nounroll
-        for (int e = tid + 256 * kHvOperandRegs; e < nV; e += 256) stage_w(e, buffer_load_real(v_rsrc, vbyte0 + e * sz));   // very long halos only
+        for (int e = tid + NTH * kOpRegs; e < nV; e += NTH) stage_w(e, buffer_load_real(v_rsrc, vbyte0 + e * sz));   // very long halos only
     }
     __syncthreads();
     stamp(0, 1);
@@ -501,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         gown[rr * KP + tpos] = oc;
         dot += (double)oc * (double)oc;
     });
-    block_allsum3(ar2, vv, dot, smem);
-    lq = block_allsum(lq, smem);                                // (its barriers also order gown before publish_rows)
+    block_allsum3<NW>(ar2, vv, dot, smem);
+    lq = block_allsum<NW>(lq, smem);                                // (its barriers also order gown before publish_rows)
     int xi = 0;                                                 // exchanges so far: index, parity and tag of the next one (identical in every workgroup)
     stamp(0, 3);
     if (tid == 0) publish(xi, ar2, vv, dot, lq);
@@ -529,9 +578,9 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     real alpha = 0;
     int it = 0;
     // iteration 0: s = 0, r = d = -g on every staged row (the halo rows of g arrived with the records)
-    for (int e = tid; e < own_n; e += 256) vs[own0 + e] = gown[e];
+    for (int e = tid; e < own_n; e += NTH) vs[own0 + e] = gown[e];
     __syncthreads();
-    for (int e = tid; e < nV; e += 256) { const real x = -vs[e]; vs[e] = x; rst[e] = x; }
+    for (int e = tid; e < nV; e += NTH) { const real x = -vs[e]; vs[e] = x; rst[e] = x; }
     __syncthreads();
     for (;;) {
         if (it > 0) {
@@ -552,7 +601,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             const real beta = rho / rho_prev;
             const real tmp = beta - (real)1.0, nalpha = -alpha;
             rho_prev_d = rho_d;
-            for (int e = tid; e < nV; e += 256) {
+            for (int e = tid; e < nV; e += NTH) {
                 real x = vs[e];
                 const uint32_t eo = (uint32_t)(e - own0);
                 if (eo < (uint32_t)own_n) sown[eo] = fma(alpha, x, sown[eo]);            // s += alpha d      (rf_tron.h:461)
@@ -575,7 +624,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
             hh += (double)oc * (double)oc;                                               // <Hd,Hd>
         });
         stamp(it + 1, 3);
-        block_allsum3(d0, rhd, hh, smem);
+        block_allsum3<NW>(d0, rhd, hh, smem);
         stamp(it + 1, 4);
         if (tid == 0) publish(xi, d0, rhd, hh, 0);
         stamp_all(it, 1);
@@ -588,12 +637,12 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     // s += alpha d, r' = r - alpha Hd (own rows; stop_it == 0: s = 0, r = -g), sums <g,s>, <s,r'>, <s,s>
     __syncthreads();
     double gs = 0, sr = 0, ss = 0;
-    for (int e = tid; e < own_n; e += 256) {
+    for (int e = tid; e < own_n; e += NTH) {
         real snew = sown[e], rnew = rst[own0 + e];
         if (stop_it >= 1) { snew = fma(alpha, vs[own0 + e], snew); rnew = fma(-alpha, hst[own0 + e], rnew); sown[e] = snew; }
         gs += (double)gown[e] * (double)snew; sr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
     }
-    block_allsum3(gs, sr, ss, smem);
+    block_allsum3<NW>(gs, sr, ss, smem);
     if (tid == 0) publish(xi, gs, sr, ss, 0);
     publish_rows(xi, sown);
     double cs[4];
@@ -602,8 +651,8 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     if (tid == 0) { keep[3] = cs[0]; keep[4] = cs[1]; keep[5] = cs[2]; }     // parked across the product below (registers)
 
     // =========================== H s and the acceptance test (hv_tile_kernel<HV_PLAIN>, accept_tile_kernel) ===========================
-    for (int e = tid; e < own_n; e += 256) vs[own0 + e] = sown[e];
-    for (int e = own_n + tid; e < TI * KP; e += 256) vs[own0 + e] = 0;     // a short last tile: rows past T
+    for (int e = tid; e < own_n; e += NTH) vs[own0 + e] = sown[e];
+    for (int e = own_n + tid; e < TI * KP; e += NTH) vs[own0 + e] = 0;     // a short last tile: rows past T
     __syncthreads();
     double sHs = 0, unused2 = 0, rdir = 0, unused3 = 0;
     if (ar_on) ar_residuals(unused2);
@@ -616,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
         const double rt = (double)gown[rr * KP + tpos] + (double)oc;
         rdir += rt * rt;
     });
-    block_allsum3(sHs, rdir, unused3, smem);
+    block_allsum3<NW>(sHs, rdir, unused3, smem);
     if (tid == 0) publish(xi, rdir, 0, sHs, 0, true);
     double ps[4];
     if (!collect(xi, 3, ps, false, nullptr)) return;
@@ -628,7 +677,7 @@ __global__ __launch_bounds__(256, 2) void cg_persist_kernel(XParams p, XState *_
     const double fnew = f - actred;
     const bool accept = actred > 1e-4 * prered;                                  // eta0, rf_tron.h:222
     if (accept)
-        for (int e = tid; e < own_n; e += 256) { real *wp = a.W + (size_t)i0 * KP + e; *wp = *wp + sown[e]; }   // w_new = w + s (rf_tron.h:183-184)
+        for (int e = tid; e < own_n; e += NTH) { real *wp = a.W + (size_t)i0 * KP + e; *wp = *wp + sown[e]; }   // w_new = w + s (rf_tron.h:183-184)
     stamp(kProfIters - 1, 0);
     if (lead) {
         const double rho = (double)(real)rho_stop;

@@ -42,7 +42,7 @@ __host__ __device__ inline size_t persist_lds_bytes(int TI, int midx, int KP, in
     const size_t vec = ((size_t)(TI + 2 * midx) * KP * sizeof(real) + 15) / 16 * 16;     // d, r, H d on the staged rows
     const size_t own = ((size_t)TI * KP * sizeof(real) + 15) / 16 * 16;                   // s, g on the own rows
     const size_t res = ((size_t)(TI + midx) * hv_res_pitch(k) * sizeof(double) + 15) / 16 * 16;
-    const size_t th = ((size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)nlag * sizeof(int) + 15) / 16 * 16;
+    const size_t th = ((size_t)nlag * KP * (sizeof(double) + sizeof(real)) + (size_t)2 * (nlag + 2) * sizeof(int) + 15) / 16 * 16;   // Theta twice, lag offsets twice
     return 3 * vec + 2 * own + res + th + (size_t)tiles * 4 * sizeof(double);             // + the collected records
 }
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void persist_peer_emulator_kernel(PeerEmuArgs 
 }
 #endif
 
-template <int KQ, bool SHARD>
+template <int KQ, bool SHARD, int NTH = 256>
 __global__ void cg_persist_kernel(XParams p, XState *__restrict__ st, PersistArgs a);      // defined in cg_persist.hpp, instantiated in unit_persist.hip
 
 }  // namespace trmf

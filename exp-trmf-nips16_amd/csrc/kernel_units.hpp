@@ -6,8 +6,9 @@
 // address is the kernel's handle in every unit (checked on the GPU: scripts/ubench/tu_split).
 //
 //   unit_hv_rep.hip    hv_tile_kernel<MODE, KQ, false>   (32)  one rank / replicated CG, launch per step
+//   unit_hv_wide.hip   hv_tile_kernel<MODE, KQ, false, 512> (32)  the same over wide tiles (512 threads; one rank)
 //   unit_hv_shard.hip  hv_tile_kernel<MODE, KQ, true>    (32)  time-sharded CG, launch per step
-//   unit_persist.hip   cg_persist_kernel<KQ, SHARD>      (16)  the persistent CG kernel
+//   unit_persist.hip   cg_persist_kernel<KQ, SHARD, NTH> (24)  the persistent CG kernel (256 threads: one rank / sharded; 512: one rank, wide tiles)
 //   unit_gram.hip      fsolve_quad / fsolve_mfma (8), gram_x_kernel (16), loss_kernel (4)
 //   unit_full.hip      the MFMA kernels of the full-observation path (20)
 //
@@ -44,29 +45,29 @@
 namespace trmf {
 
 #define TRMF_HV_SIG (XParams, XState *, HvVecs, TileShard, int, int, const uint32_t *, const real *, const real *, const double *, double *, const PeerTable *, int, int)
-#define TRMF_HV_KQS(X, MODE, SHARD)                           \
-    X void hv_tile_kernel<MODE, 8, SHARD> TRMF_HV_SIG;        \
-    X void hv_tile_kernel<MODE, 16, SHARD> TRMF_HV_SIG;       \
-    X void hv_tile_kernel<MODE, 24, SHARD> TRMF_HV_SIG;       \
-    X void hv_tile_kernel<MODE, 32, SHARD> TRMF_HV_SIG;       \
-    X void hv_tile_kernel<MODE, 40, SHARD> TRMF_HV_SIG;       \
-    X void hv_tile_kernel<MODE, 48, SHARD> TRMF_HV_SIG;       \
-    X void hv_tile_kernel<MODE, 56, SHARD> TRMF_HV_SIG;       \
-    X void hv_tile_kernel<MODE, 64, SHARD> TRMF_HV_SIG;
-#define TRMF_UNIT_HV(X, SHARD)                                                                                   \
-    TRMF_HV_KQS(X, HV_GRAD, SHARD) TRMF_HV_KQS(X, HV_CG_FIRST, SHARD) TRMF_HV_KQS(X, HV_CG_STEP, SHARD) TRMF_HV_KQS(X, HV_PLAIN, SHARD)
+#define TRMF_HV_KQS(X, MODE, SHARD, NTH)                           \
+    X void hv_tile_kernel<MODE, 8, SHARD, NTH> TRMF_HV_SIG;        \
+    X void hv_tile_kernel<MODE, 16, SHARD, NTH> TRMF_HV_SIG;       \
+    X void hv_tile_kernel<MODE, 24, SHARD, NTH> TRMF_HV_SIG;       \
+    X void hv_tile_kernel<MODE, 32, SHARD, NTH> TRMF_HV_SIG;       \
+    X void hv_tile_kernel<MODE, 40, SHARD, NTH> TRMF_HV_SIG;       \
+    X void hv_tile_kernel<MODE, 48, SHARD, NTH> TRMF_HV_SIG;       \
+    X void hv_tile_kernel<MODE, 56, SHARD, NTH> TRMF_HV_SIG;       \
+    X void hv_tile_kernel<MODE, 64, SHARD, NTH> TRMF_HV_SIG;
+#define TRMF_UNIT_HV(X, SHARD, NTH)                                                                                   \
+    TRMF_HV_KQS(X, HV_GRAD, SHARD, NTH) TRMF_HV_KQS(X, HV_CG_FIRST, SHARD, NTH) TRMF_HV_KQS(X, HV_CG_STEP, SHARD, NTH) TRMF_HV_KQS(X, HV_PLAIN, SHARD, NTH)
 
 #define TRMF_PERSIST_SIG (XParams, XState *, PersistArgs)
-#define TRMF_PERSIST_KQS(X, SHARD)                                  \
-    X void cg_persist_kernel<8, SHARD> TRMF_PERSIST_SIG;            \
-    X void cg_persist_kernel<16, SHARD> TRMF_PERSIST_SIG;           \
-    X void cg_persist_kernel<24, SHARD> TRMF_PERSIST_SIG;           \
-    X void cg_persist_kernel<32, SHARD> TRMF_PERSIST_SIG;           \
-    X void cg_persist_kernel<40, SHARD> TRMF_PERSIST_SIG;           \
-    X void cg_persist_kernel<48, SHARD> TRMF_PERSIST_SIG;           \
-    X void cg_persist_kernel<56, SHARD> TRMF_PERSIST_SIG;           \
-    X void cg_persist_kernel<64, SHARD> TRMF_PERSIST_SIG;
-#define TRMF_UNIT_PERSIST(X) TRMF_PERSIST_KQS(X, false) TRMF_PERSIST_KQS(X, true)
+#define TRMF_PERSIST_KQS(X, SHARD, NTH)                                  \
+    X void cg_persist_kernel<8, SHARD, NTH> TRMF_PERSIST_SIG;            \
+    X void cg_persist_kernel<16, SHARD, NTH> TRMF_PERSIST_SIG;           \
+    X void cg_persist_kernel<24, SHARD, NTH> TRMF_PERSIST_SIG;           \
+    X void cg_persist_kernel<32, SHARD, NTH> TRMF_PERSIST_SIG;           \
+    X void cg_persist_kernel<40, SHARD, NTH> TRMF_PERSIST_SIG;           \
+    X void cg_persist_kernel<48, SHARD, NTH> TRMF_PERSIST_SIG;           \
+    X void cg_persist_kernel<56, SHARD, NTH> TRMF_PERSIST_SIG;           \
+    X void cg_persist_kernel<64, SHARD, NTH> TRMF_PERSIST_SIG;
+#define TRMF_UNIT_PERSIST(X) TRMF_PERSIST_KQS(X, false, 256) TRMF_PERSIST_KQS(X, true, 256) TRMF_PERSIST_KQS(X, false, 512)
 
 #define TRMF_FSOLVE_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, uint32_t, uint32_t, int, real, uint32_t)
 #if defined(TRMF_F32)

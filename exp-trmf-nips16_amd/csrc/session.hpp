@@ -260,15 +260,37 @@ struct TrmfSessionImpl : SessionXPhase {
             if (rc) return kFail;
         }
         tile_TI = 0; nbt = 1; persist_state = 0; persist_shard_state = 0; persist_failed = false; persist_note.clear(); snap_iter = -1;
-        {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget
+        {   // fused Hv tile: one timestamp row per 16-byte Gram column group, if the AR halo fits a modest LDS budget.
+            // Tile geometry.  Narrow: 256 threads, hv_tile_rows(k) timestamps (25 at k = 40), up to two workgroups per CU.  Wide (round 5;
+            // one rank only): when the narrow tiles outnumber the CUs -- config 3: 400 tiles on 256 CUs, 144 CUs carry two workgroups
+            // and the persistent kernel's pass is as slow as those -- and ceil(T / CUs) timestamps fit a 512-thread workgroup, ONE
+            // workgroup per CU with that many timestamps (config 3: 250 tiles of 40): the halo rows are staged once per CU instead
+            // of twice and every CU carries the same load (pass 16.7 -> 14.7 us, profiles/r05_wide_tiles.txt).  Both CG forms
+            // (persistent kernel, launch per step) have both geometries and are bit-identical to each other WITHIN a geometry; several
+            // ranks always use the narrow one (a rank owns 1/N of the tiles), so TRMF_TEST + TRMF_TILE=narrow is what reproduces an
+            // N-rank run bit for bit on one GPU.
             int TI = hv_tile_rows(k);
+            tile_nth = 256;
             if (const char *e = test_env("TRMF_HV_TI")) TI = std::max(1, std::min(TI, atoi(e)));   // experiments
             // the tile kernel addresses the CG vectors with 32-bit byte offsets through buffer descriptors
             const bool fits32 = (uint64_t)(T + 1) * KP * sizeof(real) < 0x7fffffffull;
-            if (!generic && fits32 && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= 48 * 1024 && !test_env("TRMF_NO_HV_TILE")) {
+            const bool tiles_ok = !generic && fits32 && !test_env("TRMF_NO_HV_TILE");
+            const char *tk = test_env("TRMF_TILE");                 // narrow | wide (wide: also where the rule would not choose it)
+            if (tiles_ok && comm->world == 1 && !(tk && tk[0] == 'n') && !test_env("TRMF_HV_TI")) {
+                hipDeviceProp_t prop;
+                int dev = 0;
+                TRMF_HIP_CHECK(hipGetDevice(&dev));
+                TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+                const int cus = std::max(1, prop.multiProcessorCount), rows_wide = hv_tile_rows(k, 512), need = (T + cus - 1) / cus;
+                int wide_TI = 0;
+                if (tk && tk[0] == 'w') wide_TI = std::min(rows_wide, std::max(need, TI + 1));
+                else if ((T + TI - 1) / TI > cus && need <= rows_wide) wide_TI = need;
+                if (wide_TI > 0 && hv_tile_lds_bytes(wide_TI, midx, KP, nlag, k) <= 64 * 1024) { TI = wide_TI; tile_nth = 512; }
+            }
+            if (tiles_ok && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= (tile_nth == 512 ? 64 : 48) * 1024) {
                 tile_TI = TI;
                 nbt = (T + TI - 1) / TI;                     // one tile per workgroup
-            }
+            } else tile_nth = 256;
         }
         // The cached Grams: k x k per timestamp for the fused kernel; the unfused path's product streams them once per CG
         // step and nothing else (1.64 GB per step at config 5), so there only the upper triangle is kept (packed_gram_elems)
@@ -540,7 +562,9 @@ struct TrmfSessionImpl : SessionXPhase {
             snprintf(buf, sizeof buf, "1 rank; X-solve %s", generic ? "unfused; generic kernels for rank > 64 (Gram build, F-solve)"
                      : tile_TI <= 0 ? "unfused (AR tile + cached-Gram product per CG step)"
                      : persist_state == 1 ? "fused, one persistent kernel per solve" : persist_state == 0 ? "fused (not run yet)" : "fused, one launch per CG step");
-            return persist_note.empty() ? std::string(buf) : std::string(buf) + " (" + persist_note + ")";
+            std::string d(buf);
+            if (!generic && tile_TI > 0) { snprintf(buf, sizeof buf, "; %d tiles of %d timestamps, %d threads", nbt, tile_TI, tile_nth); d += buf; }
+            return persist_note.empty() ? d : d + " (" + persist_note + ")";
         }
         const bool fused = tile_TI > 0;
         std::string x;

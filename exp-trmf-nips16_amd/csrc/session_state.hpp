@@ -70,6 +70,7 @@ struct SessionState {
     DevBuf<real> gen_scratch, theta_scratch;  // k x k systems of the generic F-solve; |L| x |L| systems of long lag sets
     bool gpacked = false;                     // unfused path: G holds upper triangles (packed_gram_elems(k) per timestamp), apply_kernel<true>
     int tile_TI = 0, nbt = 1;                 // fused Hv kernel: timestamps per tile (0 = unfused path), tiles of the problem
+    int tile_nth = 256;                       // threads of a tile's workgroup: 256, or 512 (wide tiles, one rank: one workgroup per CU)
     // fused path: per-tile records of each launch (cg_kernels.hpp "per-tile partial records") in three message buffers:
     // CG launches of even / odd iteration, gradient + plain launch.  tsh: the one-rank view (one slot, every tile);
     // tsh_rank: this rank's block of tiles when the CG is sharded over time (ts_possible).
@@ -253,22 +254,22 @@ struct SessionState {
     DevBuf<long long> persist_prof;           // -DTRMF_PERSIST_PROF builds: phase stamps of the last solve (printed by sync())
     uint32_t persist_epoch = 1;
     int persist_state = 0;                    // 0: not examined yet, 1: usable, -1: not
-    template <int KQ, bool SHARD = false> int persist_prepare(size_t lds) {
-        const void *fn = reinterpret_cast<const void *>(&cg_persist_kernel<KQ, SHARD>);
+    template <int KQ, bool SHARD = false, int NTH = 256> int persist_prepare(size_t lds) {
+        const void *fn = reinterpret_cast<const void *>(&cg_persist_kernel<KQ, SHARD, NTH>);
         if (lds > kLdsMax) return 0;
         if (lds > kLdsDefault && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, NTH, lds) != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
             hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         // (256-thread blocks are admitted per CU up to min(API answer, 8, 800 / (ceil(sgprs / 16) * 16 + 16)), same guide: 6 at this
         // kernel's ~106 SGPRs -- the register-bound answer of 2..3 is always the smaller one; capped anyway)
-        return std::min(per_cu, 4) * prop.multiProcessorCount;
+        return std::min(per_cu, NTH == 256 ? 4 : 1) * prop.multiProcessorCount;
     }
-    template <int KQ, bool SHARD = false> int persist_launch(const PersistArgs &pa, size_t lds) {
+    template <int KQ, bool SHARD = false, int NTH = 256> int persist_launch(const PersistArgs &pa, size_t lds) {
         // a plain launch: the grid was checked against the occupancy in persist_prepare(); hipLaunchCooperativeKernel gives the same
         // residency for 15-19 us more host time per launch (MI355X guide, "coop-launch")
-        hipLaunchKernelGGL((cg_persist_kernel<KQ, SHARD>), dim3(SHARD ? tsh_rank.ntiles : nbt), dim3(256), lds, stream, xp, xstate.p, pa);
+        hipLaunchKernelGGL((cg_persist_kernel<KQ, SHARD, NTH>), dim3(SHARD ? tsh_rank.ntiles : nbt), dim3(NTH), lds, stream, xp, xstate.p, pa);
         TRMF_HIP_CHECK(hipGetLastError());
         return 0;
     }

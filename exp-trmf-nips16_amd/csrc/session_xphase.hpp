@@ -173,9 +173,14 @@ struct SessionXPhase : SessionFPhase {
         const TileShard &sh = SHARD ? tsh_rank : tsh;
         const PeerTable *pt = (SHARD && p2p_use) ? peer_table.p : nullptr;
         const int mi = rec_out == xm[0] ? 0 : rec_out == xm[1] ? 1 : 2;
+        // (wide tiles -- 512 threads, one rank only: session.hpp, choose_tile() -- have their own instantiations, unit_hv_wide.hip)
 #define TRMF_LAUNCH_HV_KQ(KQ)                                                                                        \
-        hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ, SHARD>), dim3(sh.ntiles), dim3(256), lds, stream, xp, xstate.p, a, sh, it, last,  \
-                           lag_set.p, theta.p, Gmat(), rec_in, rec_out, pt, mi, tile_TI)
+        if (!SHARD && tile_nth == 512)                                                                               \
+            hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ, false, 512>), dim3(sh.ntiles), dim3(512), lds, stream, xp, xstate.p, a, sh, it, last,  \
+                               lag_set.p, theta.p, Gmat(), rec_in, rec_out, pt, mi, tile_TI);                         \
+        else                                                                                                         \
+            hipLaunchKernelGGL((hv_tile_kernel<MODE, KQ, SHARD>), dim3(sh.ntiles), dim3(256), lds, stream, xp, xstate.p, a, sh, it, last,  \
+                               lag_set.p, theta.p, Gmat(), rec_in, rec_out, pt, mi, tile_TI)
         switch (hv_kq(k) / 8) {
             case 1: TRMF_LAUNCH_HV_KQ(8); break;
             case 2: TRMF_LAUNCH_HV_KQ(16); break;
@@ -234,6 +239,9 @@ struct SessionXPhase : SessionFPhase {
         if (shard)
             hipLaunchKernelGGL(cg_close_kernel<true>, dim3(sh.ntiles), dim3(256), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
                                dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
+        else if (tile_nth == 512)
+            hipLaunchKernelGGL((cg_close_kernel<false, 512>), dim3(sh.ntiles), dim3(512), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
+                               dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
         else
             hipLaunchKernelGGL(cg_close_kernel<false>, dim3(sh.ntiles), dim3(256), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
                                dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
@@ -243,8 +251,11 @@ struct SessionXPhase : SessionFPhase {
         launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs> (fields [0..2] of the same records)
         if (shard && exchange(2, -1, 0, nullptr, nullptr, nullptr)) return kFail;
         const int nb = (int)std::min<size_t>(kMaxPartials, ((size_t)(sh.row_e - sh.row_b) * KP + 255) / 256);
-        hipLaunchKernelGGL(accept_tile_kernel, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mg, sh,
-                           shard ? 1 : 0, w_new.p, W.p, log_x, log_n);
+        if (!shard && tile_nth == 512)                 // (the records are summed in the tiles' own order: thread stride = workgroup size)
+            hipLaunchKernelGGL(accept_tile_kernel<512>, dim3(std::max(nb, 1)), dim3(512), 0, stream, xp, xstate.p, mg, sh, 0, w_new.p, W.p, log_x, log_n);
+        else
+            hipLaunchKernelGGL(accept_tile_kernel<256>, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mg, sh,
+                               shard ? 1 : 0, w_new.p, W.p, log_x, log_n);
         TRMF_HIP_CHECK(hipGetLastError());
         if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return 0;
@@ -269,7 +280,7 @@ struct SessionXPhase : SessionFPhase {
             // between the ranks' kernels); never where ranks share a device (their workgroups would have to be co-resident)
             if ((comm->world == 1 || max_ranks_per_device == 1) && tile_TI > 0 && nbt <= kPersistMaxTiles && maxcg <= kCgHistCap && !(e && atoi(e) == 0)) {
                 int slots = 0;
-#define TRMF_PERSIST_PREP(KQV) slots = persist_prepare<KQV>(lds)
+#define TRMF_PERSIST_PREP(KQV) slots = tile_nth == 512 ? persist_prepare<KQV, false, 512>(lds) : persist_prepare<KQV>(lds)
                 TRMF_PERSIST_SWITCH(TRMF_PERSIST_PREP)
 #undef TRMF_PERSIST_PREP
                 if (slots >= nbt && ll_rec.alloc((size_t)2 * nbt * kLLWords) == 0 &&
@@ -342,7 +353,7 @@ struct SessionXPhase : SessionFPhase {
             hipLaunchKernelGGL(persist_peer_emulator_kernel, dim3(1), dim3(256), 0, side, ea);
             TRMF_HIP_CHECK(hipGetLastError());
         }
-#define TRMF_PERSIST_GO(KQV) if (shard ? persist_launch<KQV, true>(pa, lds) : persist_launch<KQV, false>(pa, lds)) return kFail
+#define TRMF_PERSIST_GO(KQV) if (shard ? persist_launch<KQV, true>(pa, lds) : tile_nth == 512 ? persist_launch<KQV, false, 512>(pa, lds) : persist_launch<KQV, false>(pa, lds)) return kFail
         TRMF_PERSIST_SWITCH(TRMF_PERSIST_GO)
 #undef TRMF_PERSIST_GO
         if (emu_done) {

@@ -4,5 +4,5 @@
 #include "kernel_units.hpp"
 
 namespace trmf {
-TRMF_UNIT_HV(TRMF_DEFINE_KERNEL, false)
+TRMF_UNIT_HV(TRMF_DEFINE_KERNEL, false, 256)
 }  // namespace trmf

@@ -4,5 +4,5 @@
 #include "kernel_units.hpp"
 
 namespace trmf {
-TRMF_UNIT_HV(TRMF_DEFINE_KERNEL, true)
+TRMF_UNIT_HV(TRMF_DEFINE_KERNEL, true, 256)
 }  // namespace trmf

@@ -8,6 +8,8 @@
   with one rank it is covered below (all-gather degenerates to a no-op)."""
 import socket
 
+import os
+
 import numpy as np
 import pytest
 
@@ -77,10 +79,19 @@ def test_two_ranks_one_gpu_match_single_process(shape):
 
 
 def _single_process(p, m0, dtype, iters):
+    """The one-process run the N-rank runs are compared with bit for bit: in the tile geometry several ranks always use (one rank
+    alone takes WIDE tiles where the narrow ones outnumber the CUs -- config 3 at full size; same iterates up to rounding, not
+    bit for bit: tests/test_gpu_persist.py)."""
     from trmf import session, synth
     model = make_model(m0.W.astype(dtype), m0.H.astype(dtype), np.asfortranarray(m0.lag_val.astype(dtype)), p['lag_set'])
-    with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
-        s.run(iters); st = s.stats(iters); s.download()
+    old = os.environ.get('TRMF_TILE')
+    os.environ['TRMF_TILE'] = 'narrow'
+    try:
+        with session.Session(p['Y'].astype(dtype), model, missing=True, **synth.HYPER) as s:
+            s.run(iters); st = s.stats(iters); s.download()
+    finally:
+        if old is None: os.environ.pop('TRMF_TILE', None)
+        else: os.environ['TRMF_TILE'] = old
     return model, [x['cg_iter'] for x in st]
 
 
