@@ -885,7 +885,7 @@ __global__ void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, Til
                                                          const double *__restrict__ rec_in, double *__restrict__ rec_out,
                                                          const PeerTable *__restrict__ pt, int mi, int TI);
 #else
-template <int MODE, int KQ, bool SHARD, int NTH>
+template <int MODE, int KQ, bool SHARD, int NTH = 256>
 __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void hv_tile_kernel(XParams p, XState *__restrict__ st, HvVecs a, TileShard sh,
                                                          int it, int last,
                                                          const uint32_t *__restrict__ lag_set,

@@ -601,13 +601,45 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
             const real beta = rho / rho_prev;
             const real tmp = beta - (real)1.0, nalpha = -alpha;
             rho_prev_d = rho_d;
-            for (int e = tid; e < nV; e += NTH) {
-                real x = vs[e];
-                const uint32_t eo = (uint32_t)(e - own0);
-                if (eo < (uint32_t)own_n) sown[eo] = fma(alpha, x, sown[eo]);            // s += alpha d      (rf_tron.h:461)
-                const real rnew = fma(nalpha, hst[e], rst[e]);                           // r -= alpha Hd     (rf_tron.h:489-490)
-                x = fma(tmp, x, x); x = x + rnew;                                        // d = beta d + r    (rf_tron.h:497-499)
-                rst[e] = rnew; vs[e] = x;
+            // element-wise, no sums: any assignment of elements to threads gives the same vectors.  One 16-byte vector of neighbouring
+            // elements per thread and array, two trips' worth requested before the first use (all of nV, own0, own_n are multiples of
+            // 16): 7 trips of three dependent LDS round trips each became 2 trips of one (the ISA of the scalar form: ds_read -> branch
+            // -> ds_read -> wait -> ds_write -> ds_read x2 -> wait -> ds_write x2 per element).
+            {
+                constexpr int EV = 16 / (int)sizeof(real);
+                typedef VecOf<real, EV> V;
+                const int tq = opaque((int)threadIdx.x) * EV;
+#pragma nounroll
+                for (int e0 = 0; e0 < nV; e0 += 2 * EV * NTH) {
+                    V xq[2], hq[2], rq[2], sq[2];
+                    int e[2]; bool in[2], own[2];
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        e[m] = e0 + tq + EV * NTH * m;
+                        in[m] = e[m] < nV;
+                        const int ec = in[m] ? e[m] : 0;
+                        own[m] = in[m] && (uint32_t)(ec - own0) < (uint32_t)own_n;
+                        xq[m] = *reinterpret_cast<const V *>(vs + ec);
+                        hq[m] = *reinterpret_cast<const V *>(hst + ec);
+                        rq[m] = *reinterpret_cast<const V *>(rst + ec);
+                        sq[m] = *reinterpret_cast<const V *>(sown + (own[m] ? ec - own0 : 0));
+                    }
+#pragma unroll
+                    for (int m = 0; m < 2; m++) {
+                        if (!in[m]) continue;
+                        V rn, xn, sn;
+#pragma unroll
+                        for (int c = 0; c < EV; c++) {
+                            real x = xq[m].v[c];
+                            sn.v[c] = fma(alpha, x, sq[m].v[c]);                         // s += alpha d      (rf_tron.h:461)
+                            rn.v[c] = fma(nalpha, hq[m].v[c], rq[m].v[c]);               // r -= alpha Hd     (rf_tron.h:489-490)
+                            x = fma(tmp, x, x); xn.v[c] = x + rn.v[c];                   // d = beta d + r    (rf_tron.h:497-499)
+                        }
+                        if (own[m]) *reinterpret_cast<V *>(sown + (e[m] - own0)) = sn;
+                        *reinterpret_cast<V *>(rst + e[m]) = rn;
+                        *reinterpret_cast<V *>(vs + e[m]) = xn;
+                    }
+                }
             }
             __syncthreads();
             stamp(it + 1, 1);
