@@ -215,6 +215,9 @@ struct TrmfSessionImpl : SessionXPhase {
             if (comm->allgatherv(gramx_times.p, off.data(), stream)) return kFail;
             TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         }
+        // the Theta-solve's own stream, where it will be used: acquired here, not inside somebody's timed iterations (the first
+        // hipStreamCreate of a process costs ~20 ms -- it showed up as 3 ms per iteration in a 6-iteration config-5 bench line)
+        if (nlag > 0 && theta_overlap_pays() && !test_env("TRMF_NO_OVERLAP")) (void)ensure_aux();
         created = true;
         return autotune();
     }
@@ -283,8 +286,14 @@ struct TrmfSessionImpl : SessionXPhase {
                 TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
                 const int cus = std::max(1, prop.multiProcessorCount), rows_wide = hv_tile_rows(k, 512), need = (T + cus - 1) / cus;
                 int wide_TI = 0;
+                // (the wide geometry pays through the persistent kernel; where that cannot run -- switched off, a CG cap beyond its
+                // history, LDS -- the launch-per-step path is faster on narrow tiles: 975 against 959 iter/s at config 3)
+                const int maxcg = (int)std::min<long long>(max_cg_iter, (long long)T * k);
+                const char *pe = getenv("TRMF_PERSIST");
+                const bool persist_wanted = !(pe && atoi(pe) == 0) && maxcg <= kCgHistCap;
                 if (tk && tk[0] == 'w') wide_TI = std::min(rows_wide, std::max(need, TI + 1));
-                else if ((T + TI - 1) / TI > cus && need <= rows_wide) wide_TI = need;
+                else if (persist_wanted && (T + TI - 1) / TI > cus && need <= rows_wide &&
+                         persist_lds_bytes(need, midx, KP, nlag, k, (T + need - 1) / need) <= kLdsMax) wide_TI = need;
                 if (wide_TI > 0 && hv_tile_lds_bytes(wide_TI, midx, KP, nlag, k) <= 64 * 1024) { TI = wide_TI; tile_nth = 512; }
             }
             if (tiles_ok && hv_tile_lds_bytes(TI, midx, KP, nlag, k) <= (tile_nth == 512 ? 64 : 48) * 1024) {

@@ -66,7 +66,7 @@ for N in worlds:
     ms_x, ms_xg = float(np.mean([x['ms_X'] for x in st])), float(np.mean([x['ms_X_gram'] for x in st]))
     r = dict(config=cfgname, surrogate_T=rows_n, world_equivalent=N, ms_X_gram=ms_xg, ms_CG=ms_x - ms_xg, cg_steps=cg, us_per_pass=1e3 * (ms_x - ms_xg) / (cg + 2))
     rows.append(r)
-    print('%s  one rank over the first %d timestamps (= the block of one rank at N=%d, %d tiles): X-side Gram %.3f ms   CG (one persistent kernel) %.3f ms = %.1f steps + 2 passes x %.2f us   [%s]' % (
-        cfgname, rows_n, N, (rows_n + TI - 1) // TI, ms_xg, r['ms_CG'], cg, r['us_per_pass'], desc[:70]))
+    print('%s  one rank over the first %d timestamps (= the block of one rank at N=%d; %d narrow tiles, the session says: %s): X-side Gram %.3f ms   CG (one persistent kernel) %.3f ms = %.1f steps + 2 passes x %.2f us   [%s]' % (
+        cfgname, rows_n, N, (rows_n + TI - 1) // TI, desc.split('; ')[-1], ms_xg, r['ms_CG'], cg, r['us_per_pass'], desc[:70]))
     sys.stdout.flush()
 print(json.dumps(rows))
