@@ -75,3 +75,22 @@ def test_bench_through_the_launcher_line_with_one_rank():
     r = json.loads(lines[0])
     assert r['n_gpus'] == 1 and r['steps'] == 3 and r['value'] > 0 and r['metric'] == 'als_iterations_per_sec'
     assert r['roofline']['achieved'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_falls_back_to_replicas_when_the_library_communicator_cannot_be_set_up():
+    """bench.py --gpus N must not end without a figure because the library's own RCCL communicator failed on some rank: every rank
+    drops it (agreed through torch.distributed) and runs the one-GPU solver; the line says so.  Forced here with one rank."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, TRMF_BENCH_FORCE_DIST='1', TRMF_BENCH_FAIL_DIST_INIT='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '3', '--warmup', '1',
+           '--config', 'c2', '--no-cpu-baseline']
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+    r = json.loads(lines[0])
+    assert r['value'] > 0 and 'replicas of the one-GPU solver' in r['config']['parallelism']
