@@ -12,7 +12,9 @@ all-gathers over xGMI), so total work is fixed: "scaling": 
 
 Rank 0 prints ONE JSON line.  `roofline` describes the F-solve kernel (HBM-bound under the
 gather-inclusive algorithmic byte model B_F of SURVEY.md 8(d) / BASELINE.md section 3), timed with HIP
-events recorded on the solver's own stream around that kernel; `roofline_compute` prices the same launch in useful
+events recorded on the solver's own stream around that kernel -- on every third iteration of the timed window (--timing 3: an
+iteration's seven phase events are barrier packets that cost ~25 us, so they are sampled; `value` is wall clock over ALL iterations;
+profiles/r05b_events.txt) --; `roofline_compute` prices the same launch in useful
 arithmetic against the dtype's matrix peak (config 5's fp64 F-solve is bound by that, not by HBM).  `cpu_baseline` times the reference's
 CPU path (oracle/_ref when present, else the C restatement) on this box's host cores with the protocol of
 BASELINE.md section 3 (min(physical, 64) and 8 threads, 2 warm-up + 10 timed iterations from the state the
@@ -241,6 +243,11 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='c3')
+    ap.add_argument('--timing', type=int, default=3,
+                    help='phase events (F / X / Theta split, kernel times of the roofline objects) on every N-th iteration of the timed '
+                         'window; 1 = every iteration.  The seven event records of an iteration cost 21-26 us (2.5 %% of a config-3 '
+                         'iteration, 22 %% of a config-2 one): the default samples every third iteration, which alternates between '
+                         'iterations with and without a Theta-solve')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'persist', 'shard'],
                     help='multi-GPU CG form (sets TRMF_CG; default: the library measures replicated vs time-sharded)')
@@ -329,7 +336,7 @@ def main():
 
     t_up = time.perf_counter()
     # verbose=0 run of the reference: no ||.||^2 log lines (trmf.cpp:659-688 evaluates them only under verbose)
-    s = session.Session(prob['Y'], model, missing=missing, log_norms=False, **hyper)
+    s = session.Session(prob['Y'], model, missing=missing, log_norms=False, timing=max(1, args.timing), **hyper)
     t_up = time.perf_counter() - t_up
     s.run(args.warmup)
     device_sync(s); barrier()
@@ -364,10 +371,11 @@ def main():
     if replicas_note:
         described = replicas_note + '; each: ' + described
     bytes_f = s.fsolve_bytes()
-    ms_fk = float(np.mean([x['ms_F_kernel'] for x in st]))
-    ms_xg = float(np.mean([x['ms_X_gram'] for x in st]))
-    ms_x = float(np.mean([x['ms_X'] for x in st]))
-    cg_steps = float(np.mean([x['cg_iter'] for x in st]))
+    timed = [x for x in st if x['ms_F'] >= 0] or st        # the iterations of the window that carried phase events (--timing)
+    ms_fk = float(np.mean([x['ms_F_kernel'] for x in timed]))
+    ms_xg = float(np.mean([x['ms_X_gram'] for x in timed]))
+    ms_x = float(np.mean([x['ms_X'] for x in timed]))
+    cg_steps = float(np.mean([x['cg_iter'] for x in timed]))   # of the same iterations (us per pass = their CG time / their passes)
     s.download()
     s.close()
 
@@ -397,8 +405,8 @@ def main():
                 # DESIGN.md section 6): F rows / X-side Gram rows sharded or replicated, the CG replicated or sharded over time with the
                 # exchange through RCCL or peer to peer -- with the slowest rank's measured X phase of every candidate
                 'parallelism': described,
-                'phases_ms_rank0': {'F': float(np.mean([x['ms_F'] for x in st])), 'X': float(np.mean([x['ms_X'] for x in st])),
-                                    'Theta': float(np.mean([x['ms_LV'] for x in st]))}},
+                'phases_ms_rank0': {'F': float(np.mean([x['ms_F'] for x in timed])), 'X': float(np.mean([x['ms_X'] for x in timed])),
+                                    'Theta': float(np.mean([x['ms_LV'] for x in timed]))}},
             'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_mfma_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
@@ -416,9 +424,13 @@ def main():
                     157.3 if dtype == np.float32 else 78.6, 155.0 if dtype == np.float32 else 50.3),
             'roofline_x': roofline_x(cfg, nnz, dtype, missing, world, ms_xg, ms_x, cg_steps, described),
             'one_shot': one_shot,
-            'phases_ms': {'F': float(np.mean([x['ms_F'] for x in st])), 'X': float(np.mean([x['ms_X'] for x in st])),
-                          'Theta': float(np.mean([x['ms_LV'] for x in st])),
-                          'cg_iter': [int(x['cg_iter']) for x in st]},
+            'phases_ms': {'F': float(np.mean([x['ms_F'] for x in timed])), 'X': float(np.mean([x['ms_X'] for x in timed])),
+                          'Theta': float(np.mean([x['ms_LV'] for x in timed])),
+                          'cg_iter': [int(x['cg_iter']) for x in st],
+                          'timed_iterations': len(timed), 'of': len(st),
+                          'note': 'HIP events of the iterations that carried them (every %d-th of the window; each such iteration pays seven event '
+                                  'records, ~25 us, the others none -- value / ms_per_step are wall clock over ALL iterations); F / X / Theta '
+                                  'overlap where the Theta-solve runs on its own stream under the next F-solve' % max(1, args.timing)},
             'setup_s': {'generate': t_gen, 'upload_and_alloc': t_up},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -438,8 +450,18 @@ def main():
                 # the CPU runs its first `cpu_iters` iterations from the state the GPU's timed window started from; later iterations
                 # run shorter CG solves, so the like-for-like GPU figure is the one over the SAME iterations, from the
                 # per-iteration HIP-event phase times
-                w = st[:min(args.cpu_iters, len(st))]
-                base['gpu_same_window'] = {'iters': len(w), 'iter_per_s': 1e3 * len(w) / sum(x['ms_F'] + x['ms_X'] + x['ms_LV'] for x in w)}
+                # -- wall clock around a session that repeats exactly those iterations from that state (the second of two: the first
+                # warms the pool and the kernels' attributes), no phase events
+                if state_file:
+                    z = np.load(state_file)
+                    from trmf import Model
+                    n_it = args.cpu_iters
+                    for attempt in range(2):
+                        m3 = Model.from_arrays(z['W'], z['H'], z['lag_val'], prob['lag_set'])
+                        with session.Session(prob['Y'], m3, missing=missing, log_norms=False, timing=0, **hyper) as s3:
+                            s3.sync()
+                            t3 = time.perf_counter(); s3.run(n_it); s3.sync(); t3 = time.perf_counter() - t3
+                    base['gpu_same_window'] = {'iters': n_it, 'iter_per_s': n_it / t3, 'clock': 'wall clock around run() + sync()'}
                 out['cpu_baseline'] = base
             for f in (state_file, gpu_file):
                 if f and os.path.exists(f):

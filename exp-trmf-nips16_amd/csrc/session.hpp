@@ -611,6 +611,9 @@ struct TrmfSessionImpl : SessionXPhase {
             const int iter1 = ++iter;                       // 1-based like the reference
             DeviceIterLog *L = log.p + ((iter1 - 1) % kLogCap);
             PhaseEvents &ev = events[(iter1 - 1) % kEventRing];
+            ev_on = ev_period > 0 && (iter1 % ev_period) == 0;
+            if (ev_valid.size() != (size_t)kEventRing) ev_valid.assign(kEventRing, 0);
+            ev_valid[(iter1 - 1) % kEventRing] = ev_on ? 1 : 0;
             static const DeviceIterLog blank = [] { DeviceIterLog b; std::memset(&b, 0, sizeof b); b.normF = b.normX = b.normLV = -1; return b; }();
             const bool doF = period_H > 0 && (iter1 % period_H) == 0;
             const bool doX = period_W > 0 && (iter1 % period_W) == 0;
@@ -619,20 +622,20 @@ struct TrmfSessionImpl : SessionXPhase {
             // phases fill it in (two small copies per iteration on the stream)
             const bool device_log = doX && !log_norms && !verbose;
             if (!device_log) TRMF_HIP_CHECK(hipMemcpyAsync(L, &blank, sizeof blank, hipMemcpyHostToDevice, stream));
-            TRMF_HIP_CHECK(hipEventRecord(ev.f0, stream));
+            TRMF_EVREC(ev.f0, stream);
             if (doF) {
                 if (full ? fsolve_full(ev) : fsolve(ev)) return kFail;
                 if (log_norms || verbose) log_norm(H.p, (size_t)n * KP, &L->normF);
                 if (verbose) fprintf(stderr, ">> iter %d F %g\n", iter1, host_double(&L->normF));
             } else {
-                TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
-                TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+                TRMF_EVREC(ev.fk0, stream);
+                TRMF_EVREC(ev.fk1, stream);
             }
-            TRMF_HIP_CHECK(hipEventRecord(ev.f1, stream));
-            if (!doX) TRMF_HIP_CHECK(hipEventRecord(ev.xg1, stream));
+            TRMF_EVREC(ev.f1, stream);
+            if (!doX) TRMF_EVREC(ev.xg1, stream);
             if (doX) {
                 if (join_theta()) return kFail;              // the X-solve reads Theta (and writes W, which the Theta-solve reads)
-                xg1_event = ev.xg1;
+                xg1_event = ev_on ? ev.xg1 : nullptr;
                 const int xrc = xsolve(device_log ? &L->x : nullptr, device_log ? &L->normF : nullptr);
                 xg1_event = nullptr;
                 if (xrc) return kFail;
@@ -650,7 +653,7 @@ struct TrmfSessionImpl : SessionXPhase {
                     }
                 }
             }
-            TRMF_HIP_CHECK(hipEventRecord(ev.x1, stream));
+            TRMF_EVREC(ev.x1, stream);
             if (doL) {
                 if (verbose) {
                     log_norm(theta.p, (size_t)nlag * k, &L->normLV);
@@ -663,7 +666,7 @@ struct TrmfSessionImpl : SessionXPhase {
                     TRMF_HIP_CHECK(hipEventRecord(theta_fork, stream));
                     TRMF_HIP_CHECK(hipStreamWaitEvent(aux_theta, theta_fork, 0));
                     if (theta_solve(aux_theta)) return kFail;
-                    TRMF_HIP_CHECK(hipEventRecord(ev.lv1, aux_theta));
+                    TRMF_EVREC(ev.lv1, aux_theta);
                     TRMF_HIP_CHECK(hipEventRecord(theta_done, aux_theta));
                     theta_pending = true;
                     continue;
@@ -672,7 +675,7 @@ struct TrmfSessionImpl : SessionXPhase {
                 if (log_norms || verbose) log_norm(theta.p, (size_t)nlag * k, &L->normLV);
                 if (verbose) fprintf(stderr, ">> iter %d LV %g\n", iter1, host_double(&L->normLV));
             }
-            TRMF_HIP_CHECK(hipEventRecord(ev.lv1, stream));
+            TRMF_EVREC(ev.lv1, stream);
         }
         return join_theta();
     }
@@ -784,7 +787,8 @@ struct TrmfSessionImpl : SessionXPhase {
             o.f = hl.x.f; o.fnew = hl.x.fnew; o.actred = hl.x.actred; o.prered = hl.x.prered;
             o.gnorm = hl.x.gnorm; o.cg_rnorm = hl.x.cg_rnorm; o.cg_iter = hl.x.cg_iter; o.accepted = hl.x.accepted; o.delta = hl.x.delta;
             o.cg_rnorm_direct = hl.x.rho_direct >= 0 ? std::sqrt(hl.x.rho_direct) : -1.0;
-            o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = o.ms_X_gram = 0;
+            o.ms_F = o.ms_X = o.ms_LV = o.ms_F_kernel = o.ms_X_gram = -1;
+            if (ev_valid.size() != (size_t)kEventRing || !ev_valid[it0 % kEventRing]) continue;      // no phase events in that iteration (ev_period)
             (void)hipEventElapsedTime(&o.ms_X_gram, ev.f1, ev.xg1);
             (void)hipEventElapsedTime(&o.ms_F, ev.f0, ev.f1);
             (void)hipEventElapsedTime(&o.ms_F_kernel, ev.fk0, ev.fk1);

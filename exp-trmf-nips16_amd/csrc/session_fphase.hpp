@@ -110,12 +110,12 @@ struct SessionFPhase : SessionTransport {
             }
             const uint64_t rowbytes = (uint64_t)KP * sizeof(real);
             const uint64_t *mine = fcut.data() + (size_t)comm->rank * (C + 1);
-            TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+            TRMF_EVREC(ev.fk0, stream);
             for (int c = 0; c < C; c++) {
                 if (launch_fsolve_rows((uint32_t)mine[c], (uint32_t)mine[c + 1])) return kFail;
                 if (c + 1 < C) TRMF_HIP_CHECK(hipEventRecord(ov_c[c], stream));
             }
-            TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+            TRMF_EVREC(ev.fk1, stream);
             TRMF_HIP_CHECK(hipGetLastError());
             fs_calls++;
             std::vector<uint64_t> gb(W_), ge(W_);
@@ -133,9 +133,9 @@ struct SessionFPhase : SessionTransport {
             return 0;
         }
         if (measure) TRMF_HIP_CHECK(hipEventRecord(fs0, stream));
-        TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        TRMF_EVREC(ev.fk0, stream);
         if (launch_fsolve_rows(rb, re)) return kFail;
-        TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+        TRMF_EVREC(ev.fk1, stream);
         TRMF_HIP_CHECK(hipGetLastError());
         fs_calls++;
         if (replicate) return 0;                                    // every rank solved every row: nothing to gather
@@ -224,7 +224,7 @@ struct SessionFPhase : SessionTransport {
     }
     int fsolve_full(PhaseEvents &ev) {
         const uint32_t rb = (uint32_t)fbounds[comm->rank], re = (uint32_t)fbounds[comm->rank + 1];
-        TRMF_HIP_CHECK(hipEventRecord(ev.fk0, stream));
+        TRMF_EVREC(ev.fk0, stream);
         // (W^T W + lambda I and its factor do not depend on Y^T W, but running them beside it on a second stream was measured and is
         // not faster: the fork / join events cost more than the ~60 us chain they would hide; profiles/r05_streams.txt)
         hipStream_t gs = stream;
@@ -248,7 +248,7 @@ struct SessionFPhase : SessionTransport {
             hipLaunchKernelGGL(solve_rows_kernel, dim3(nblk), dim3(256), ulds, stream, Uf.p, Bf.p + (size_t)rb * KP,
                                H.p + (size_t)rb * KP, nrows, k, KP, NT);
         }
-        TRMF_HIP_CHECK(hipEventRecord(ev.fk1, stream));
+        TRMF_EVREC(ev.fk1, stream);
         TRMF_HIP_CHECK(hipGetLastError());
         return gather_rows(H.p, fbounds, (size_t)KP * sizeof(real));
     }

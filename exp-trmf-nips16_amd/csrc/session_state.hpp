@@ -310,6 +310,16 @@ struct SessionState {
     struct PartialRef { int slot, kind; };
 
     hipEvent_t xg1_event = nullptr;           // this iteration's PhaseEvents::xg1 (set by run())
+    // Phase events of an iteration (TrmfIterStats.ms_*): seven hipEventRecords.  They are not free: each is a barrier packet between
+    // two kernels that would otherwise be dispatched back to back -- measured 21-26 us per iteration (config 3: +2.5 % iterations/s
+    // without them, config 2: +22 %, profiles/r05b_events.txt).  ev_period (trmf_session_set_timing): 1 = every iteration (default of
+    // a session: every TrmfIterStats carries times), N > 1 = the iterations whose 1-based index is a multiple of N (bench.py: 3, so
+    // that the samples alternate between iterations with and without a Theta-solve), 0 = none (c_trmf_train: nobody reads them).
+    // An iteration without events reports ms_* = -1.
+    int ev_period = 1;
+    bool ev_on = true;                        // this iteration (set by run())
+    std::vector<unsigned char> ev_valid;      // per slot of the event ring: that iteration's events were recorded
+#define TRMF_EVREC(EV, STREAM) do { if (ev_on) TRMF_HIP_CHECK(hipEventRecord(EV, STREAM)); } while (0)
 
     // Dynamic LDS above the 64 KB every launch may use needs an explicit opt-in per kernel (gfx950: up to 160 KB
     // per workgroup); anything larger is an unsupported problem, reported instead of a failed launch.

@@ -552,7 +552,7 @@ struct SessionXPhase : SessionFPhase {
         } else {
             if (gram_x(shard)) return kFail;                                   // G, b
         }
-        if (xg1_event) TRMF_HIP_CHECK(hipEventRecord(xg1_event, stream));
+        if (xg1_event) TRMF_EVREC(xg1_event, stream);
         if (p2p_use && (fused ? shard : uts)) p2p_fence(fused ? tsh_rank : ush);
         auto end_timed = [&]() -> int {
             if (!timed) return 0;

@@ -189,6 +189,7 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
         return;
     }
     s->log_norms = verbose > 0;                      // the norm lines exist only under verbose (trmf.cpp:659-688)
+    s->ev_period = 0;                                // nobody reads per-phase times of a one-shot call (they cost 21-26 us per iteration)
     const double t1 = TrmfSessionImpl::now_s();
     int rc = s->run(max_iter);
     if (rc == 0) rc = s->sync();
@@ -278,6 +279,11 @@ int32_t trmf_session_run(TrmfSession *s, int32_t iters) {
 int32_t trmf_session_log_norms(TrmfSession *s, int32_t on) {
     if (!s) return kFail;
     IMPL(s)->log_norms = on != 0;
+    return 0;
+}
+int32_t trmf_session_set_timing(TrmfSession *s, int32_t period) {
+    if (!s || period < 0) return kFail;
+    IMPL(s)->ev_period = period;
     return 0;
 }
 int32_t trmf_session_sync(TrmfSession *s) {

@@ -57,6 +57,7 @@ def bind(lib):
     lib.trmf_session_create.restype = c_void_p
     lib.trmf_session_run.argtypes = [c_void_p, c_int32]; lib.trmf_session_run.restype = c_int32
     lib.trmf_session_log_norms.argtypes = [c_void_p, c_int32]; lib.trmf_session_log_norms.restype = c_int32
+    lib.trmf_session_set_timing.argtypes = [c_void_p, c_int32]; lib.trmf_session_set_timing.restype = c_int32
     lib.trmf_session_sync.argtypes = [c_void_p]; lib.trmf_session_sync.restype = c_int32
     lib.trmf_session_append_rows.argtypes = [c_void_p, P]; lib.trmf_session_append_rows.restype = c_int32
     lib.trmf_session_rows.argtypes = [c_void_p]; lib.trmf_session_rows.restype = c_int32
@@ -97,7 +98,7 @@ class Session(object):
     """``Session(Y, model, **hyper).run(iters)``; the model's arrays are refreshed by ``download()``."""
 
     def __init__(self, Y, model, lambdaI=0.1, lambdaAR=0.1, lambdaLag=0.1,
-                 period_W=1, period_H=1, period_Lag=2, missing=True, verbose=0, log_norms=True):
+                 period_W=1, period_H=1, period_Lag=2, missing=True, verbose=0, log_norms=True, timing=1):
         self.model = model
         self.lib = lib_for(model.W.dtype)
         self.pyY = Y if isinstance(Y, PyMatrix) else PyMatrix(Y, dtype=model.W.dtype)
@@ -109,6 +110,8 @@ class Session(object):
             raise RuntimeError('trmf_session_create failed: ' + self.lib.trmf_last_error().decode())
         if not log_norms:       # the reference computes the ||.||^2 log lines only under verbose
             self.lib.trmf_session_log_norms(self.handle, 0)
+        if timing != 1:         # phase events (ms_* of stats()) on every `timing`-th iteration only / never (0): they cost ~25 us apiece
+            self._check(self.lib.trmf_session_set_timing(self.handle, int(timing)), 'trmf_session_set_timing')
 
     def _check(self, rc, what):
         if rc < 0:

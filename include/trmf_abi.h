@@ -153,7 +153,8 @@ typedef struct {
     double f, fnew, actred, prered;        /* X-subproblem objective before/after, reductions  */
     double gnorm, cg_rnorm;
     int32_t cg_iter, accepted;
-    float ms_F, ms_X, ms_LV;               /* HIP-event time of each phase on the solver stream */
+    float ms_F, ms_X, ms_LV;               /* HIP-event time of each phase on the solver stream; all ms_* are -1 for an
+                                              iteration that carried no events (trmf_session_set_timing)         */
     float ms_F_kernel;                     /* HIP-event time of the F-solve kernel alone       */
     double delta;                          /* trust-region bound of the TRON line (rf_tron.h:195-219) */
     double cg_rnorm_direct;                /* |-g - H s| of the step evaluated directly; cg_rnorm is the CG's recurrence
@@ -181,6 +182,12 @@ TRMF_API int32_t trmf_session_run(TrmfSession *s, int32_t iters);
  * reference evaluates these norms only under `verbose` (trmf.cpp:659-688); with the switch off the
  * fields read -1 and an iteration is about 30 us shorter.  c_trmf_train follows `verbose`.        */
 TRMF_API int32_t trmf_session_log_norms(TrmfSession *s, int32_t on);
+/* Which iterations carry the HIP events behind TrmfIterStats.ms_*: 1 = every iteration (default), N > 1 = the iterations whose
+ * 1-based index is a multiple of N, 0 = none.  The seven event records of an iteration are barrier packets between kernels that
+ * would otherwise be dispatched back to back: 21-26 us per iteration on an MI355X (2.5 % of a config-3 iteration, 22 % of a
+ * config-2 one).  An iteration without events reports ms_* = -1; everything else of its record is unaffected.  c_trmf_train
+ * records none.  No reference counterpart.                                                                                      */
+TRMF_API int32_t trmf_session_set_timing(TrmfSession *s, int32_t period);
 /* Append Ynew (Tn x n, NEW timestamps, same storage class -- sparse or dense -- as the session's Y) to the resident
  * problem: the rolling-window caller of the reference (python/trmf/trmf.py:303-329) retrains on a prefix that
  * grows by one window and warm-starts from the previous model (trmf.py:237-246).  Only the block (and, for a

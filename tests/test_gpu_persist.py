@@ -171,3 +171,27 @@ def test_wide_tiles_both_cg_forms_bit_identical_and_equal_to_narrow_up_to_roundi
         assert np.linalg.norm(u.astype(np.float64) - v.astype(np.float64)) <= tol * np.linalg.norm(v.astype(np.float64))
     assert all(abs(x['cg_iter'] - y['cg_iter']) <= 1 for x, y in zip(sa, sn))
     assert all(abs(x['f'] - y['f']) <= (1e-8 if dtype == np.float64 else 1e-5) * abs(y['f']) for x, y in zip(sa, sn))
+
+
+def test_phase_events_on_every_nth_iteration_only(monkeypatch):
+    """trmf_session_set_timing: the seven HIP event records behind TrmfIterStats.ms_* are instrumentation (barrier packets between
+    kernels, ~25 us per iteration): with period N only the iterations whose 1-based index is a multiple of N carry them, the others
+    report ms_* = -1; with 0 none does.  Everything else of the records and the factors is unaffected."""
+    from trmf import session, synth
+    p = synth.sparse_problem(n=900, T=400, k=12, nlag=4, density=0.06, dtype=np.float32, seed=31)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], 12, seed=31)
+    out = {}
+    for timing in (1, 3, 0):
+        model = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), p['lag_set'])
+        with session.Session(p['Y'].astype(np.float32), model, missing=True, log_norms=False, timing=timing, **synth.HYPER) as s:
+            s.run(4); s.run(5); st = s.stats(9); s.download()
+        out[timing] = (model, st)
+    for timing in (3, 0):
+        assert np.array_equal(out[timing][0].W, out[1][0].W) and np.array_equal(out[timing][0].H, out[1][0].H)
+        assert [x['cg_iter'] for x in out[timing][1]] == [x['cg_iter'] for x in out[1][1]]
+        assert [x['f'] for x in out[timing][1]] == [x['f'] for x in out[1][1]]
+    assert all(x['ms_F'] > 0 and x['ms_X'] > 0 and x['ms_F_kernel'] > 0 for x in out[1][1])
+    for i, x in enumerate(out[3][1]):                     # iterations 1..9
+        carried = (i + 1) % 3 == 0
+        assert (x['ms_F'] > 0 and x['ms_X'] > 0 and x['ms_X_gram'] > 0) if carried else (x['ms_F'] == -1 and x['ms_X'] == -1 and x['ms_LV'] == -1), (i, x)
+    assert all(x['ms_F'] == -1 and x['ms_F_kernel'] == -1 for x in out[0][1])
