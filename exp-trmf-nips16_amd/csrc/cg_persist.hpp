@@ -89,6 +89,12 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
     constexpr int NT_T = (KQ + kTile - 1) / kTile;
     constexpr int KP = kTile * NT_T;
     constexpr int RPITCH = KQ;
+    // LDS layout of the fp64 residual rows and of lambdaAR * Theta (this kernel only; the arithmetic does not see it).  The adjoint reads a
+    // thread's VEC values of either as 16-byte vectors; with VEC = 4 (fp32, rank <= 40) that was two ds_read_b128 at a 32-byte lane
+    // stride -- a 16-lane group then covers 32 sixteen-byte slots of a 16-slot bank row: 2-way conflicts by construction, 3/4 of the
+    // kernel's bank-conflict cycles.  The values are therefore kept in NPL planes of EPP values per thread: plane h of
+    // all rows first, so that the wave's read of a plane is one contiguous range again.
+    constexpr int NPL = VEC * 8 >= 32 ? 2 : 1, EPP = VEC / NPL, RPP = RPITCH / NPL, TPP = KP / NPL;
     const int tid = threadIdx.x;
     const int k = p.k, T = p.T, Hh = p.midx, nlag = p.nlag, TI = a.TI;
     const int rowsV = TI + 2 * Hh, rowsR = TI + Hh, nV = rowsV * KP, nTh = nlag * k;
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
     double *rs = reinterpret_cast<double *>(hv_smem + 3 * vecb + 2 * ownb);
     double *thd = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(rs) + (((size_t)rowsR * RPITCH * sizeof(double) + 15) / 16 * 16));
     real *thp = reinterpret_cast<real *>(thd + (size_t)nlag * KP);
-    // the lag set as the two element offsets the phases need (lag * KP into the staged operand, lag * RPITCH into the residual rows),
+    // the lag set as the two element offsets the phases need (lag * KP into the staged operand, lag * RPP into a plane of the residual rows),
     // two spare entries each: a loop over pairs of lags reads the NEXT pair's offsets while it works on the current one
     int *lagv = reinterpret_cast<int *>(thp + (size_t)nlag * KP);
     int *lagq = lagv + nlag + 2;
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
         auto put = [&](int e, real th) {
             const int tt = e / nlag, l = e - tt * nlag;
             thp[l * KP + colpos(tt, NT_T)] = th;
-            thd[l * KP + tt] = p.lambdaAR * (double)th;
+            thd[(((tt % VEC) / EPP) * nlag + l) * TPP + (tt / VEC) * EPP + tt % EPP] = p.lambdaAR * (double)th;
         };
 #pragma unroll
         for (int m = 0; m < kThRegs; m++)
@@ -186,11 +192,11 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
         for (int e = tid; e < nlag * (KP - k); e += NTH) {
             const int l = e / (KP - k), tt = k + (e - l * (KP - k));
             thp[l * KP + colpos(tt, NT_T)] = 0;
-            thd[l * KP + tt] = 0;
+            thd[(((tt % VEC) / EPP) * nlag + l) * TPP + (tt / VEC) * EPP + tt % EPP] = 0;
         }
-        if (tid < nlag) { lagv[tid] = lagr * KP; lagq[tid] = lagr * RPITCH; }
+        if (tid < nlag) { lagv[tid] = lagr * KP; lagq[tid] = lagr * RPP; }
 #pragma nounroll
-        for (int e = tid + NTH; e < nlag; e += NTH) { const int lg = (int)a.lag_set[e]; lagv[e] = lg * KP; lagq[e] = lg * RPITCH; }
+        for (int e = tid + NTH; e < nlag; e += NTH) { const int lg = (int)a.lag_set[e]; lagv[e] = lg * KP; lagq[e] = lg * RPP; }
         if (tid < 2) { lagv[nlag + tid] = 0; lagq[nlag + tid] = 0; }
     }
     for (int e = tid; e < nV; e += NTH) { rst[e] = 0; hst[e] = 0; }
@@ -431,7 +437,7 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
                     const double rv2 = on[u] ? res[u][c] : 0.0;
                     if (it < items && tl < k) {
                         if (rr < TI) ar2 += rv2 * rv2;
-                        rs[rr * RPITCH + tl] = rv2;
+                        rs[(((tl % VEC) / EPP) * rowsR + rr) * RPP + (tl / VEC) * EPP + tl % EPP] = rv2;
                     }
                 }
             }
@@ -455,32 +461,46 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
         }
         if (ar_on) {
             {
-                const VecOf<double, VEC> r0 = *reinterpret_cast<const VecOf<double, VEC> *>(rs + rr * RPITCH + t0);
+                const double *r0p = rs + rr * RPP + (t0 / VEC) * EPP;
 #pragma unroll
-                for (int c = 0; c < VEC; c++) od[c] += p.lambdaAR * r0.v[c];
+                for (int h = 0; h < NPL; h++) {
+                    const VecOf<double, EPP> r0 = *reinterpret_cast<const VecOf<double, EPP> *>(r0p + h * rowsR * RPP);
+#pragma unroll
+                    for (int e = 0; e < EPP; e++) od[h * EPP + e] += p.lambdaAR * r0.v[e];
+                }
             }
             // (lags in pairs, the next pair's residual-row offsets requested ahead: see ar_residuals)
-            const double *rrow = rs + rr * RPITCH + t0;
+            const double *rrow = rs + rr * RPP + (t0 / VEC) * EPP;            // plane 0; plane h: + h * rowsR * RPP
+            const double *trow = thd + (t0 / VEC) * EPP;                       // plane 0 of lag 0; plane h of lag l: + (h * nlag + l) * TPP
+            const int rplane = rowsR * RPP, tplane = nlag * TPP;
             int qn0 = lagq[0], qn1 = lagq[1];
             int l = 0;
 #pragma nounroll
             for (; l + 1 < nlag; l += 2) {
                 const int q0 = qn0, q1 = qn1;
-                const VecOf<double, VEC> ra = *reinterpret_cast<const VecOf<double, VEC> *>(rrow + q0);
-                const VecOf<double, VEC> ta = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
-                const VecOf<double, VEC> rb = *reinterpret_cast<const VecOf<double, VEC> *>(rrow + q1);
-                const VecOf<double, VEC> tb = *reinterpret_cast<const VecOf<double, VEC> *>(thd + (l + 1) * KP + t0);
+                VecOf<double, EPP> ra[NPL], ta[NPL], rb[NPL], tb[NPL];
+#pragma unroll
+                for (int h = 0; h < NPL; h++) {
+                    ra[h] = *reinterpret_cast<const VecOf<double, EPP> *>(rrow + h * rplane + q0);
+                    ta[h] = *reinterpret_cast<const VecOf<double, EPP> *>(trow + h * tplane + l * TPP);
+                    rb[h] = *reinterpret_cast<const VecOf<double, EPP> *>(rrow + h * rplane + q1);
+                    tb[h] = *reinterpret_cast<const VecOf<double, EPP> *>(trow + h * tplane + (l + 1) * TPP);
+                }
                 qn0 = lagq[l + 2]; qn1 = lagq[l + 3];
 #pragma unroll
-                for (int c = 0; c < VEC; c++) od[c] -= ra.v[c] * ta.v[c];
+                for (int c = 0; c < VEC; c++) od[c] -= ra[c / EPP].v[c % EPP] * ta[c / EPP].v[c % EPP];
 #pragma unroll
-                for (int c = 0; c < VEC; c++) od[c] -= rb.v[c] * tb.v[c];
+                for (int c = 0; c < VEC; c++) od[c] -= rb[c / EPP].v[c % EPP] * tb[c / EPP].v[c % EPP];
             }
             if (l < nlag) {
-                const VecOf<double, VEC> ra = *reinterpret_cast<const VecOf<double, VEC> *>(rrow + qn0);
-                const VecOf<double, VEC> ta = *reinterpret_cast<const VecOf<double, VEC> *>(thd + l * KP + t0);
+                VecOf<double, EPP> ra[NPL], ta[NPL];
 #pragma unroll
-                for (int c = 0; c < VEC; c++) od[c] -= ra.v[c] * ta.v[c];
+                for (int h = 0; h < NPL; h++) {
+                    ra[h] = *reinterpret_cast<const VecOf<double, EPP> *>(rrow + h * rplane + qn0);
+                    ta[h] = *reinterpret_cast<const VecOf<double, EPP> *>(trow + h * tplane + l * TPP);
+                }
+#pragma unroll
+                for (int c = 0; c < VEC; c++) od[c] -= ra[c / EPP].v[c % EPP] * ta[c / EPP].v[c % EPP];
             }
         }
         double acc[VEC];
