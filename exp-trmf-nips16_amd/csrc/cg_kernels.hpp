@@ -59,10 +59,30 @@ struct XParams {
 // Fixed-order block reductions (blockDim.x == 256 = 4 wavefronts).  Butterfly inside the wavefront
 // (no barrier), then the four wave sums are combined in a fixed order: deterministic, identical in
 // every thread, two barriers instead of a nine-barrier LDS tree.
+// (Round 5: the xor butterfly `v += __shfl_xor(v, m)` for m = 1 .. 32 compiled to twelve ds_bpermute_b32 per sum -- LDS-pipe round trips
+// in a dependent chain, ~0.25 us per block sum, twice per CG pass.  The same tree -- pairs, quads, halves of a 16-lane row, rows, (r0 + r1)
+// + (r2 + r3) -- through DPP row operations and four lane reads: every add has the operands of the butterfly's, possibly swapped, and
+// IEEE addition is commutative, so the result is BIT-IDENTICAL to the butterfly's in every lane.)
+template <int CTRL> __device__ __forceinline__ double dpp_move_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned long long)(unsigned int)lo));
+}
+__device__ __forceinline__ double read_lane_f64(double v, int lane) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, lane);
+    const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
 __device__ __forceinline__ double wave_butterfly_sum(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    v += dpp_move_f64<0xB1>(v);        // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_move_f64<0x4E>(v);        // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp_move_f64<0x141>(v);       // row_half_mirror: the other quad of the 8-lane half
+    v += dpp_move_f64<0x140>(v);       // row_mirror: the other half of the 16-lane row
+    const double r0 = read_lane_f64(v, 0), r1 = read_lane_f64(v, 16), r2 = read_lane_f64(v, 32), r3 = read_lane_f64(v, 48);
+    // lanes of rows 0 / 1 hold (r0 + r1) after the butterfly's xor-16 step, rows 2 / 3 (r2 + r3); its xor-32 step adds the two
+    return (r0 + r1) + (r2 + r3);
 }
 // NW = wavefronts of the workgroup: 4 (256 threads, every kernel but the wide tiles) or 8 (512 threads: the wide tiles of
 // cg_persist_kernel / hv_tile_kernel / cg_close_kernel); wave sums combined pairwise in index order

@@ -37,7 +37,7 @@ def _train_windows_resident(Y, lag_set, k, cuts, seed, hyper, max_iter, missing,
     from .session import Session
     model = Model.initialize(Y[:cuts[0]], lag_set, k, seed=seed, transform=transform)
     with Session(_as_training_matrix(Y[:cuts[0]], missing), model, missing=missing, verbose=verbose,
-                 log_norms=bool(verbose), **hyper) as sess:
+                 log_norms=bool(verbose), timing=0, **hyper) as sess:      # (nobody reads per-phase times here: no phase events)
         if model.transform is not None:
             sess.set_transform(model.transform)
         sess.run(max_iter).download()
