@@ -371,13 +371,21 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
     // unrolled work item -- out of the loop and keep it in registers for the whole kernel: with the Gram slice resident there is
     // no room for that.  Each phase therefore derives its indices from an OPAQUE copy of the thread index.)
     auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
-    constexpr int kResU = 1;          // work items a thread carries through the lag loop (hv_tile_kernel: kHvResU = 2; no registers for that here)
+    // Work items a thread may carry through the lag loop TOGETHER (their LDS round trips overlap): two, like hv_tile_kernel's kHvResU.  A
+    // wavefront takes the second one only if any of its lanes has one (wave-uniform): at 672 items on 512 threads that is wavefronts 0-2,
+    // which used to run a second round of eight dependent trips alone while the other five idled at the barrier.
+    // (one where the Gram slice leaves no room: fp64 at rank 33..40 -- 160 registers of slice, 8 per staged quad)
+    constexpr int kResU = (sizeof(real) == 8 && KQ * VEC * (int)sizeof(real) / 4 >= 160) ? 1 : 2;
     auto ar_residuals = [&](double &ar2) {
         constexpr int NG = KP / 4;
         const int items = rowsR * NG;
         const int tid = opaque((int)threadIdx.x);
 #pragma nounroll
         for (int it0 = 0; it0 < items; it0 += NTH * kResU) {
+            // a wavefront none of whose lanes has a work item in this round leaves (wave-uniform)
+            const int wave_first = __builtin_amdgcn_readfirstlane(it0 + (tid & ~63));
+            if (wave_first >= items) break;
+            const bool two = kResU == 2 && wave_first + NTH < items;           // wave-uniform: some lane of this wavefront has a second item
             int vb[kResU], pg[kResU];
             bool on[kResU];
             double res[kResU][4];
@@ -396,37 +404,51 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
             // offset that is itself read from LDS: as a plain loop every lag cost TWO dependent LDS round trips (offset, then operand;
             // seen in the ISA: ds_read2_b32 -> s_waitcnt -> v_mul_lo -> ds_read_b128 -> s_waitcnt).  The offsets are now stored
             // pre-multiplied and the next pair's are requested behind this pair's operands: one round trip per pair.
-            static_assert(kResU == 1, "one work item per thread in the persistent kernel");
-            int bn0 = lagv[0], bn1 = lagv[1];
-            int l = 0;
+            auto lag_loop = [&](auto uc) {
+                constexpr int U = decltype(uc)::value;
+                int bn0 = lagv[0], bn1 = lagv[1];
+                int l = 0;
 #pragma nounroll
-            for (; l + 1 < nlag; l += 2) {
-                const int b0 = bn0, b1 = bn1;
-                const Quad<real> tha = *reinterpret_cast<const Quad<real> *>(thp + l * KP + pg[0]);
-                const Quad<real> thb = *reinterpret_cast<const Quad<real> *>(thp + (l + 1) * KP + pg[0]);
-                const Quad<real> xa = *reinterpret_cast<const Quad<real> *>(vs + vb[0] - b0);
-                const Quad<real> xb = *reinterpret_cast<const Quad<real> *>(vs + vb[0] - b1);
-                bn0 = lagv[l + 2]; bn1 = lagv[l + 3];
+                for (; l + 1 < nlag; l += 2) {
+                    const int b0 = bn0, b1 = bn1;
+                    Quad<real> tha[U], thb[U], xa[U], xb[U];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const real prod = tha.v[c] * xa.v[c];
-                    res[0][c] -= (double)prod;
-                }
+                    for (int u = 0; u < U; u++) {
+                        tha[u] = *reinterpret_cast<const Quad<real> *>(thp + l * KP + pg[u]);
+                        thb[u] = *reinterpret_cast<const Quad<real> *>(thp + (l + 1) * KP + pg[u]);
+                        xa[u] = *reinterpret_cast<const Quad<real> *>(vs + vb[u] - b0);
+                        xb[u] = *reinterpret_cast<const Quad<real> *>(vs + vb[u] - b1);
+                    }
+                    bn0 = lagv[l + 2]; bn1 = lagv[l + 3];
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const real prod = thb.v[c] * xb.v[c];
-                    res[0][c] -= (double)prod;
-                }
-            }
-            if (l < nlag) {
-                const Quad<real> tha = *reinterpret_cast<const Quad<real> *>(thp + l * KP + pg[0]);
-                const Quad<real> xa = *reinterpret_cast<const Quad<real> *>(vs + vb[0] - bn0);
+                    for (int u = 0; u < U; u++) {
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const real prod = tha.v[c] * xa.v[c];
-                    res[0][c] -= (double)prod;
+                        for (int c = 0; c < 4; c++) {
+                            const real prod = tha[u].v[c] * xa[u].v[c];
+                            res[u][c] -= (double)prod;
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const real prod = thb[u].v[c] * xb[u].v[c];
+                            res[u][c] -= (double)prod;
+                        }
+                    }
                 }
-            }
+                if (l < nlag) {
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const Quad<real> tha = *reinterpret_cast<const Quad<real> *>(thp + l * KP + pg[u]);
+                        const Quad<real> xa = *reinterpret_cast<const Quad<real> *>(vs + vb[u] - bn0);
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const real prod = tha.v[c] * xa.v[c];
+                            res[u][c] -= (double)prod;
+                        }
+                    }
+                }
+            };
+            if (kResU == 2 && two) lag_loop(std::integral_constant<int, kResU>{});
+            else lag_loop(std::integral_constant<int, 1>{});
 #pragma unroll
             for (int u = 0; u < kResU; u++) {
                 const int it = it0 + tid + NTH * u;
@@ -446,8 +468,12 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
     // ---- (3) out = lambdaI*v + lambdaAR*AR'(v) + G.v for the thread's row and VEC columns (hv_tile_kernel phase 3); each
     //      finished element goes to `emit(rr, i, c, tcol, tpos, x, acc, od)` ----
     auto product = [&](auto &&emit) {
-        const int rr = opaque(lrc), i = i0 + rr, t0 = opaque((tid - lr * tpr) * VEC);
-        const bool live = lane_on && i < T;
+        // (row and column group re-derived from the thread index on every call -- one integer division -- instead of living in three
+        // registers for the whole kernel: the fp32 rank-40 wide instantiation spilled exactly the clamped row)
+        const int tidp = opaque((int)threadIdx.x), lrp = tidp / tpr;
+        const bool lane_on_p = lrp < TI;
+        const int rr = lane_on_p ? lrp : TI - 1, i = i0 + rr, t0 = (tidp - lrp * tpr) * VEC;
+        const bool live = lane_on_p && i < T;
         const real *vi = vs + (rr + Hh) * KP;
         double od[VEC];
 #pragma unroll
