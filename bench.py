@@ -336,6 +336,8 @@ def main():
 
     t_up = time.perf_counter()
     # verbose=0 run of the reference: no ||.||^2 log lines (trmf.cpp:659-688 evaluates them only under verbose)
+    if args.steps < 2 * max(1, args.timing):       # a window too short to hold two sampled iterations: events on every iteration
+        args.timing = 1
     s = session.Session(prob['Y'], model, missing=missing, log_norms=False, timing=max(1, args.timing), **hyper)
     t_up = time.perf_counter() - t_up
     s.run(args.warmup)
