@@ -195,3 +195,28 @@ def test_phase_events_on_every_nth_iteration_only(monkeypatch):
         carried = (i + 1) % 3 == 0
         assert (x['ms_F'] > 0 and x['ms_X'] > 0 and x['ms_X_gram'] > 0) if carried else (x['ms_F'] == -1 and x['ms_X'] == -1 and x['ms_LV'] == -1), (i, x)
     assert all(x['ms_F'] == -1 and x['ms_F_kernel'] == -1 for x in out[0][1])
+
+
+@pytest.mark.parametrize('T,expect', [(6400, '256 threads'), (6425, '512 threads'), (13056, '512 threads'), (13100, '256 threads')])
+def test_tile_geometry_rule_at_its_boundaries(T, expect, monkeypatch):
+    """The rule itself (no TRMF_TILE): at rank 40 a narrow tile holds 25 timestamps and a wide one at most 51.  6400 timestamps are
+    exactly 256 narrow tiles -> narrow; one tile more -> wide (ceil(T / CUs) timestamps per tile); 13056 = 256 x 51 is the last size
+    the wide tiles cover with one workgroup per CU; beyond it narrow again (more tiles than the persistent kernel's table: the
+    launch-per-step path).  Whatever it picks, both CG forms agree bit for bit and the factors stay within the parity gate of the
+    other geometry."""
+    from trmf import session, synth
+    lib = session.lib_for(np.float32)
+    p = synth.sparse_problem(n=1500, T=T, k=40, nlag=16, density=0.01, dtype=np.float64, seed=51)
+    m0 = synth.initial_model(p['Y'], p['lag_set'], 40, seed=51)
+    a, sa, da = _run(p, m0, np.float32, 2, True, monkeypatch, persist=True)
+    b, sb, db = _run(p, m0, np.float32, 2, True, monkeypatch, persist=False)
+    c, sc, dc = _run(p, m0, np.float32, 2, True, monkeypatch, persist=True, tile='narrow')
+    assert expect in da, da
+    if T == 13100:
+        assert 'one launch per CG step' in da, da            # 524 narrow tiles: beyond the persistent kernel's 512
+    else:
+        assert 'persistent' in da, da
+    assert np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H) and np.array_equal(a.lag_val, b.lag_val)
+    assert [x['cg_iter'] for x in sa] == [x['cg_iter'] for x in sb]
+    for u, v in ((a.W, c.W), (a.H, c.H), (a.lag_val, c.lag_val)):
+        assert np.linalg.norm(u.astype(np.float64) - v.astype(np.float64)) <= 2e-3 * np.linalg.norm(v.astype(np.float64))
