@@ -56,11 +56,7 @@ def make_problem(cfg):
     """(problem dict, hyper-parameters, missing flag) of a synth.CONFIGS entry."""
     import numpy as np
     from trmf import synth
-    dtype = np.dtype(cfg['dtype'])
-    if cfg.get('dense'):
-        return synth.dense_problem(cfg['n'], cfg['T'], cfg['k'], cfg['lags'], dtype=dtype, seed=0), dict(cfg['hyper']), False
-    return (synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=dtype, seed=0),
-            dict(synth.HYPER), True)
+    return synth.make(cfg, seed=0), dict(cfg.get('hyper', synth.HYPER)), not cfg.get('dense')
 
 
 def fsolve_source_digest():

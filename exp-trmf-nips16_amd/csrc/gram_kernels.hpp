@@ -322,6 +322,50 @@ struct SingleRowStream {
 
 constexpr int kRingDepth = 4;      // groups per iteration of gram_ring (rows padded to a multiple)
 
+// ---- split rows (round 6): rows too long for the static row -> wavefront mapping ---------------------------------------------
+// The reference schedules rows dynamically (trmf.cpp:371 `schedule(dynamic,64)`, :234,252,273 `schedule(dynamic,32)`) and is
+// indifferent to a row's length; here a row's entries are streamed by ONE wavefront, so a long row -- a densely observed series
+// (the paper's data used for imputation: 370 rows of ~21 000 entries), a hub item or a fully observed timestamp of a power-law
+// pattern -- is a serial chain that the rest of the chip waits for.  Rows of at least `thresh` entries (session_state.hpp:
+// LongRows, decided per orientation at set-up) therefore leave the row kernels (which skip them) and are cut into ITEMS of
+// contiguous entries:
+//   gram_part_kernel      one wavefront per item: gram_ring over the item's entries -> a partial Gram (+ rhs) in the MFMA
+//                         accumulator layout, stored to a slab (16 B per lane and tile: whole cache lines);
+//   fsolve_*_long_kernel / gram_x_long_kernel
+//                         the row kernels' second halves (+lambda, factorisation, substitutions -> the row of F; G_i / b_i of
+//                         a timestamp) fed by the sum of the row's partials IN ITEM ORDER -- a fixed order, so the result does
+//                         not depend on the launch geometry or the rank count.
+// Within an item the contraction runs in CSR order like everywhere else; across items the partial sums are added left to right.
+// That is a different rounding from the reference's single chain (by about an ulp of the row's Gram per item); rows below the
+// threshold are computed exactly as before.
+struct SplitRows {
+    const uint32_t *rows;      // ids of the long rows, ascending
+    const uint32_t *first;     // first item of long row i (i = 0 .. count: one past the last at the end)
+    const real *slab;          // partial Grams, `stride` reals per item
+    uint32_t stride;
+    uint32_t begin, end;       // positions of the long-row list this launch covers
+};
+template <int NT> __host__ __device__ constexpr uint32_t split_part_reals(bool with_b) {
+    return (uint32_t)(NT * (NT + 1) / 2) * 4u * kWave + (with_b ? (uint32_t)NT * kWave : 0u);
+}
+// st <- sum of the partials of items [i0, i1), left to right (the first addition is to an exact zero)
+template <int NT, bool WITH_B>
+__device__ __forceinline__ void sum_partials(GramState<NT> &st, const SplitRows &sp, uint32_t i0, uint32_t i1, int lane) {
+    typedef typename Mfma16<real>::acc_t acc_t;
+    constexpr int NTT = NT * (NT + 1) / 2;
+    st.clear();
+    const real *p = sp.slab + (size_t)i0 * sp.stride + 4 * lane;
+#pragma unroll 2
+    for (uint32_t it = i0; it < i1; it++, p += sp.stride) {
+#pragma unroll
+        for (int t = 0; t < NTT; t++) st.acc[t] += *reinterpret_cast<const acc_t *>(p + t * 4 * kWave);
+        if constexpr (WITH_B) {
+#pragma unroll
+            for (int q = 0; q < NT; q++) st.b[q] += p[NTT * 4 * kWave - 3 * lane + q * kWave];
+        }
+    }
+}
+
 #if !defined(TRMF_F32)
 __device__ __forceinline__ void wave_lds_sync() {       // LDS operations of one wavefront retire in order
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -399,16 +443,19 @@ __global__ void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
                                                                           const real *__restrict__ X,
                                                                           real *__restrict__ F, uint32_t row_begin,
                                                                           uint32_t row_end, int k, real lambda,
-                                                                          uint32_t zero_row);
-#else
+                                                                          uint32_t zero_row, uint32_t long_m1);
 template <int NT, int KMAX, bool TRAIL_MFMA = (TRMF_TRAIL_MFMA != 0)>
-__global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
+__global__ void fsolve_mfma_long_kernel(SplitRows sp, real *__restrict__ F, int k, real lambda);
+#else
+// LONG: the system of a split row -- one wavefront per long row, its Gram and right-hand side are the sum of the row's partials
+template <int NT, int KMAX, bool TRAIL_MFMA, bool LONG>
+__device__ __forceinline__ void fsolve_mfma_body(const uint32_t *__restrict__ ptr,
                                                                           const uint32_t *__restrict__ idx,
                                                                           const real *__restrict__ val,
                                                                           const real *__restrict__ X,
                                                                           real *__restrict__ F, uint32_t row_begin,
                                                                           uint32_t row_end, int k, real lambda,
-                                                                          uint32_t zero_row) {
+                                                                          uint32_t zero_row, uint32_t long_m1, const SplitRows &sp) {
     static_assert(sizeof(real) == 8, "the in-accumulator F-solve is the fp64 path");
     constexpr int KP = kTile * NT, NPAN = KMAX / 4;
     constexpr int CP = 10;                                // doubles per column record: R'0 R'1 R'2 R'3 | S0 S1 S2 S3 | 2 pad (80-byte pitch)
@@ -418,18 +465,24 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
     __shared__ __attribute__((aligned(16))) real scr_s[4][SCR];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
-    if (row >= row_end) return;                         // wave-uniform; no block barrier below
-    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
-    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
-    if (p0 == p1) return;                               // trmf.cpp:374: empty rows stay untouched
     real *ps = scr_s[wave];
     typedef typename Mfma16<real>::acc_t acc_t;
     typedef VecOf<real, 2> pair_t;
-
     GramState<NT> st;
-    st.clear();
-    {
+    uint32_t row;
+    if constexpr (LONG) {
+        const uint32_t li = sp.begin + blockIdx.x * 4u + (uint32_t)wave;
+        if (li >= sp.end) return;                       // wave-uniform; no block barrier below
+        row = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.rows[li]);
+        sum_partials<NT, true>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]),
+                               (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li + 1]), lane);
+    } else {
+        row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
+        if (row >= row_end) return;                     // wave-uniform; no block barrier below
+        const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
+        const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
+        if (p1 - p0 - 1u >= long_m1) return;            // trmf.cpp:374: empty rows stay untouched; long rows: fsolve_mfma_long_kernel
+        st.clear();
         real nowq[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) nowq[q] = 0;
@@ -590,6 +643,20 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const
     });
     if (lane < k) F[(size_t)row * KP + colpos(lane, NT)] = y * dinv;
 }
+template <int NT, int KMAX, bool TRAIL_MFMA = (TRMF_TRAIL_MFMA != 0)>
+__global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_kernel(const uint32_t *__restrict__ ptr,
+                                                                          const uint32_t *__restrict__ idx,
+                                                                          const real *__restrict__ val,
+                                                                          const real *__restrict__ X,
+                                                                          real *__restrict__ F, uint32_t row_begin,
+                                                                          uint32_t row_end, int k, real lambda,
+                                                                          uint32_t zero_row, uint32_t long_m1) {
+    fsolve_mfma_body<NT, KMAX, TRAIL_MFMA, false>(ptr, idx, val, X, F, row_begin, row_end, k, lambda, zero_row, long_m1, SplitRows{});
+}
+template <int NT, int KMAX, bool TRAIL_MFMA = (TRMF_TRAIL_MFMA != 0)>
+__global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_long_kernel(SplitRows sp, real *__restrict__ F, int k, real lambda) {
+    fsolve_mfma_body<NT, KMAX, TRAIL_MFMA, true>(nullptr, nullptr, nullptr, nullptr, F, 0u, 0u, k, lambda, 0u, 0u, sp);
+}
 #endif
 #endif  // !TRMF_F32
 
@@ -711,13 +778,16 @@ __device__ __forceinline__ void quad_factor_solve(quad_f4 (&a4)[NT][KMAX / 4], f
 struct QuadStream {
     uint32_t pr[5];   // CSR pointers of the quad's rows (wave-uniform)
     uint32_t step;    // entries per iteration = 4 * D
+    uint32_t long_m1; // (split threshold - 1): rows of at least that many entries belong to the split path (split_rows below)
     __device__ __forceinline__ uint32_t row_ptr_at(int i) const {
         return i == 0 ? pr[0] : i == 1 ? pr[1] : i == 2 ? pr[2] : i == 3 ? pr[3] : pr[4];
     }
+    // rows this stream leaves alone: empty ones (trmf.cpp:374) and long ones -- one unsigned compare: len - 1 wraps for len = 0
+    __device__ __forceinline__ bool skips(int r) const { return row_ptr_at(r + 1) - row_ptr_at(r) - 1u >= long_m1; }
     __device__ __forceinline__ GramDesc first() const {
         GramDesc d{0, 0, -1};
         for (int r = 0; r < 4; r++)
-            if (row_ptr_at(r + 1) > row_ptr_at(r)) { d = GramDesc{row_ptr_at(r), row_ptr_at(r + 1), r}; break; }
+            if (!skips(r)) { d = GramDesc{row_ptr_at(r), row_ptr_at(r + 1), r}; break; }
         return d;
     }
     __device__ __forceinline__ void operator()(GramDesc &d) const {
@@ -725,7 +795,7 @@ struct QuadStream {
         d.e0 += step;
         if (d.e0 < d.end) return;
         int r = d.row + 1;
-        while (r < 4 && row_ptr_at(r + 1) == row_ptr_at(r)) r++;       // skip empty rows (trmf.cpp:374)
+        while (r < 4 && skips(r)) r++;
         if (r < 4) d = GramDesc{row_ptr_at(r), row_ptr_at(r + 1), r};
         else d = GramDesc{0, 0, -1};
     }
@@ -748,24 +818,29 @@ __global__ void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
                                                           const float *__restrict__ X,
                                                           float *__restrict__ F, uint32_t row_begin,
                                                           uint32_t row_end, int k, float lambda,
-                                                          uint32_t zero_row);
+                                                          uint32_t zero_row, uint32_t long_m1);
+template <int NT, int KMAX>
+__global__ void fsolve_quad_long_kernel(SplitRows sp, float *__restrict__ F, int k, float lambda);
 #else
-template <int NT, int KMAX, int ABL = 0>
-__global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
+// LONG: four SPLIT rows per wavefront (positions 4 q .. 4 q + 3 of the long-row list): each system is the sum of its row's partials
+// (sum_partials) instead of a stream of entries; finalisation, factorisation and substitutions are the same code.
+template <int NT, int KMAX, int ABL, bool LONG>
+__device__ __forceinline__ void fsolve_quad_body(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,
                                                           const float *__restrict__ val,
                                                           const float *__restrict__ X,
                                                           float *__restrict__ F, uint32_t row_begin,
                                                           uint32_t row_end, int k, float lambda,
-                                                          uint32_t zero_row) {
+                                                          uint32_t zero_row, uint32_t long_m1, const SplitRows &sp) {
     static_assert(sizeof(real) == 4, "quad F-solve is the fp32 path");
     constexpr int KP = kTile * NT;
     constexpr int SLAB = quad_slab_floats<NT>();
     __shared__ __attribute__((aligned(16))) float lds_slab[4][SLAB];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 4, c = lane & 15;
-    const uint32_t row0 = row_begin + (blockIdx.x * 4u + (uint32_t)wave) * 4u;
-    if (row0 >= row_end) return;                        // wave-uniform; no block barrier below
+    // first row of the quad (LONG: first position of the long-row list)
+    const uint32_t row0 = LONG ? sp.begin + (blockIdx.x * 4u + (uint32_t)wave) * 4u : row_begin + (blockIdx.x * 4u + (uint32_t)wave) * 4u;
+    if (row0 >= (LONG ? sp.end : row_end)) return;      // wave-uniform; no block barrier below
     float *S = lds_slab[wave];
     typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -782,9 +857,11 @@ __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const 
 
     QuadStream stream;
     stream.step = 4u * kRingDepth;
-    {   // row pointers of the quad as wave-uniform scalars
+    stream.long_m1 = long_m1;
+    {   // row pointers of the quad (LONG: the item ranges of its four split rows) as wave-uniform scalars
         const uint32_t rr = row0 + (uint32_t)(lane < 5 ? lane : 4);
-        const uint32_t v = ptr[rr < row_end ? rr : row_end];
+        const uint32_t lim = LONG ? sp.end : row_end;
+        const uint32_t v = (LONG ? sp.first : ptr)[rr < lim ? rr : lim];
 #pragma unroll
         for (int i = 0; i < 5; i++) stream.pr[i] = (uint32_t)__builtin_amdgcn_readlane((int)v, i);
     }
@@ -836,7 +913,13 @@ __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const 
         st.clear();
     };
 
-    if constexpr (!(ABL & 1)) {
+    if constexpr (LONG) {
+        for (int sys = 0; sys < 4; sys++) {             // wave-uniform: item ranges of positions past the list's end are empty
+            if (stream.row_ptr_at(sys + 1) == stream.row_ptr_at(sys)) continue;
+            sum_partials<NT, !PAD>(st, sp, stream.row_ptr_at(sys), stream.row_ptr_at(sys + 1), lane);
+            finalize(sys);
+        }
+    } else if constexpr (!(ABL & 1)) {
         float nowq[NT];
 #pragma unroll
         for (int q = 0; q < NT; q++) nowq[q] = 0;
@@ -850,8 +933,25 @@ __global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const 
         RealVec<NT> o;
 #pragma unroll
         for (int q = 0; q < NT; q++) o.v[q] = (kTile * q + c < k) ? x[q] : 0.0f;
-        *reinterpret_cast<RealVec<NT> *>(F + (size_t)(row0 + grp) * KP + NT * c) = o;
+        const uint32_t orow = LONG ? sp.rows[row0 + (uint32_t)grp] : row0 + (uint32_t)grp;
+        *reinterpret_cast<RealVec<NT> *>(F + (size_t)orow * KP + NT * c) = o;
     }
+}
+template <int NT, int KMAX, int ABL = 0>
+__global__ __launch_bounds__(256, quad_waves(NT)) void fsolve_quad_kernel(const uint32_t *__restrict__ ptr,
+                                                          const uint32_t *__restrict__ idx,
+                                                          const float *__restrict__ val,
+                                                          const float *__restrict__ X,
+                                                          float *__restrict__ F, uint32_t row_begin,
+                                                          uint32_t row_end, int k, float lambda,
+                                                          uint32_t zero_row, uint32_t long_m1) {
+    fsolve_quad_body<NT, KMAX, ABL, false>(ptr, idx, val, X, F, row_begin, row_end, k, lambda, zero_row, long_m1, SplitRows{});
+}
+// (one wavefront per SIMD less than the row kernel: the partial sums want registers beside the four systems, and a launch of this
+// kernel is a few hundred wavefronts at most)
+template <int NT, int KMAX>
+__global__ __launch_bounds__(256, quad_waves(NT) - 1) void fsolve_quad_long_kernel(SplitRows sp, float *__restrict__ F, int k, float lambda) {
+    fsolve_quad_body<NT, KMAX, 0, true>(nullptr, nullptr, nullptr, nullptr, F, 0u, 0u, k, lambda, 0u, 0u, sp);
 }
 #endif
 
@@ -872,25 +972,73 @@ __global__ void gram_x_kernel(const uint32_t *__restrict__ ptr,
                                                      const real *__restrict__ Hf,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
-                                                     uint32_t zero_row, size_t gs);
-#else
+                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh);
 template <int NT, bool RHS_PAD, bool PACKED>
-__global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict__ ptr,
+__global__ void gram_x_long_kernel(SplitRows sp, real *__restrict__ G, real *__restrict__ Bv, int k, size_t gs);
+template <int NT, bool RHS_PAD>
+__global__ void gram_part_kernel(const uint32_t *__restrict__ idx, const real *__restrict__ val, const real *__restrict__ X,
+                                 const uint32_t *__restrict__ items, uint32_t item_begin, uint32_t item_end,
+                                 real *__restrict__ slab, uint32_t stride, uint32_t zero_row);
+#else
+// One wavefront per ITEM of a split row (entries [items[2 i], items[2 i + 1]) of one row): the partial Gram (+ rhs) of those
+// entries, stored in the accumulator layout -- tile t of item i at slab[i * stride + 256 t + 4 lane ..], the rhs partials of the
+// lane groups (!RHS_PAD) behind the tiles.  X / zero_row: the gathered factor and its all-zero pad row (F side: W, T; X side: H, n).
+template <int NT, bool RHS_PAD>
+__global__ __launch_bounds__(256) void gram_part_kernel(const uint32_t *__restrict__ idx, const real *__restrict__ val,
+                                                        const real *__restrict__ X, const uint32_t *__restrict__ items,
+                                                        uint32_t item_begin, uint32_t item_end, real *__restrict__ slab,
+                                                        uint32_t stride, uint32_t zero_row) {
+    typedef typename Mfma16<real>::acc_t acc_t;
+    constexpr int NTT = NT * (NT + 1) / 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t item = item_begin + blockIdx.x * 4u + (uint32_t)wave;
+    if (item >= item_end) return;                       // wave-uniform; no block barrier below
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[2 * item]);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)items[2 * item + 1]);
+    GramState<NT> st;
+    st.clear();
+    real nowq[NT];
+#pragma unroll
+    for (int q = 0; q < NT; q++) nowq[q] = 0;
+    if (p1 > p0)
+        gram_ring<NT, kRingDepth, true, false, RHS_PAD>(st, idx, val, X, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
+                                                        SingleRowStream{4u * kRingDepth}, [](int) {});
+    real *p = slab + (size_t)item * stride;
+#pragma unroll
+    for (int t = 0; t < NTT; t++) *reinterpret_cast<acc_t *>(p + t * 4 * kWave + 4 * lane) = st.acc[t];
+    if constexpr (!RHS_PAD) {
+#pragma unroll
+        for (int q = 0; q < NT; q++) p[NTT * 4 * kWave + q * kWave + lane] = st.b[q];
+    }
+}
+
+// LONG: G_i / b_i of a split timestamp row from the sum of its partials (one wavefront per long row)
+template <int NT, bool RHS_PAD, bool PACKED, bool LONG>
+__device__ __forceinline__ void gram_x_body(const uint32_t *__restrict__ ptr,
                                                      const uint32_t *__restrict__ idx,
                                                      const real *__restrict__ val,
                                                      const real *__restrict__ Hf,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
-                                                     uint32_t zero_row, size_t gs) {
+                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh, const SplitRows &sp) {
     constexpr int KP = kTile * NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
-    const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
+    GramState<NT> st;
+    uint32_t row;
+    if constexpr (LONG) {
+        const uint32_t li = sp.begin + blockIdx.x * 4u + (uint32_t)wave;
+        if (li >= sp.end) return;                       // wave-uniform; no block barrier below
+        row = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.rows[li]);
+        sum_partials<NT, !RHS_PAD>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]),
+                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li + 1]), lane);
+    } else {
+    row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
     if (row >= row_end) return;                         // wave-uniform; no block barrier below
     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
     const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
+    if (p1 - p0 >= long_thresh) return;                 // a split row: gram_x_long_kernel writes its G_i / b_i
 
-    GramState<NT> st;
     st.clear();
     real nowq[NT];
 #pragma unroll
@@ -900,6 +1048,7 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
     if (p1 > p0)
         gram_ring<NT, kRingDepth, true, false, RHS_PAD>(st, idx, val, Hf, zero_row, 4u, lane, nowq, GramDesc{p0, p1, 0},
                                                         SingleRowStream{4u * kRingDepth}, [](int) {});
+    }
     if constexpr (RHS_PAD) {                            // rhs = column KP-1 of the panel Gram: tiles (ti, NT-1), lane column 15
         if (c == 15) {
 #pragma unroll
@@ -940,6 +1089,20 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
                     }
                 }
             }
+}
+template <int NT, bool RHS_PAD, bool PACKED>
+__global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict__ ptr,
+                                                     const uint32_t *__restrict__ idx,
+                                                     const real *__restrict__ val,
+                                                     const real *__restrict__ Hf,
+                                                     real *__restrict__ G, real *__restrict__ Bv,
+                                                     uint32_t row_begin, uint32_t row_end, int k,
+                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh) {
+    gram_x_body<NT, RHS_PAD, PACKED, false>(ptr, idx, val, Hf, G, Bv, row_begin, row_end, k, zero_row, gs, long_thresh, SplitRows{});
+}
+template <int NT, bool RHS_PAD, bool PACKED>
+__global__ __launch_bounds__(256) void gram_x_long_kernel(SplitRows sp, real *__restrict__ G, real *__restrict__ Bv, int k, size_t gs) {
+    gram_x_body<NT, RHS_PAD, PACKED, true>(nullptr, nullptr, nullptr, nullptr, G, Bv, 0u, 0u, k, 0u, gs, 0u, sp);
 }
 #endif
 

@@ -10,6 +10,7 @@
 //   unit_hv_shard.hip  hv_tile_kernel<MODE, KQ, true>    (32)  time-sharded CG, launch per step
 //   unit_persist.hip   cg_persist_kernel<KQ, SHARD, NTH> (24)  the persistent CG kernel (256 threads: one rank / sharded; 512: one rank, wide tiles)
 //   unit_gram.hip      fsolve_quad / fsolve_mfma (8), gram_x_kernel (16), loss_kernel (4)
+//   unit_split.hip     the split path of long rows (round 6): gram_part_kernel (8), fsolve_*_long_kernel (8), gram_x_long_kernel (16)
 //   unit_full.hip      the MFMA kernels of the full-observation path (20)
 //
 // A unit defines TRMF_UNIT before including this file; the non-template kernels of the shared headers are compiled by the main
@@ -69,13 +70,30 @@ namespace trmf {
     X void cg_persist_kernel<64, SHARD, NTH> TRMF_PERSIST_SIG;
 #define TRMF_UNIT_PERSIST(X) TRMF_PERSIST_KQS(X, false, 256) TRMF_PERSIST_KQS(X, true, 256) TRMF_PERSIST_KQS(X, false, 512)
 
-#define TRMF_FSOLVE_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, uint32_t, uint32_t, int, real, uint32_t)
+#define TRMF_FSOLVE_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, uint32_t, uint32_t, int, real, uint32_t, uint32_t)
+#define TRMF_FSOLVE_LONG_SIG (SplitRows, real *, int, real)
 #if defined(TRMF_F32)
 #define TRMF_FSOLVE_ONE(X, NT, KMAX) X void fsolve_quad_kernel<NT, KMAX, 0> TRMF_FSOLVE_SIG;
+#define TRMF_FSOLVE_LONG_ONE(X, NT, KMAX) X void fsolve_quad_long_kernel<NT, KMAX> TRMF_FSOLVE_LONG_SIG;
 #else
 #define TRMF_FSOLVE_ONE(X, NT, KMAX) X void fsolve_mfma_kernel<NT, KMAX> TRMF_FSOLVE_SIG;
+#define TRMF_FSOLVE_LONG_ONE(X, NT, KMAX) X void fsolve_mfma_long_kernel<NT, KMAX> TRMF_FSOLVE_LONG_SIG;
 #endif
-#define TRMF_GRAMX_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, real *, uint32_t, uint32_t, int, uint32_t, size_t)
+#define TRMF_GRAMX_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, real *, uint32_t, uint32_t, int, uint32_t, size_t, uint32_t)
+// the split path of long rows (gram_kernels.hpp "split rows"): partial Grams per item, then the row kernels' second halves
+#define TRMF_GRAMX_LONG_SIG (SplitRows, real *, real *, int, size_t)
+#define TRMF_GRAM_PART_SIG (const uint32_t *, const real *, const real *, const uint32_t *, uint32_t, uint32_t, real *, uint32_t, uint32_t)
+#define TRMF_SPLIT_NT(X, NT)                                               \
+    X void gram_part_kernel<NT, true> TRMF_GRAM_PART_SIG;                  \
+    X void gram_part_kernel<NT, false> TRMF_GRAM_PART_SIG;                 \
+    X void gram_x_long_kernel<NT, true, true> TRMF_GRAMX_LONG_SIG;         \
+    X void gram_x_long_kernel<NT, true, false> TRMF_GRAMX_LONG_SIG;        \
+    X void gram_x_long_kernel<NT, false, true> TRMF_GRAMX_LONG_SIG;        \
+    X void gram_x_long_kernel<NT, false, false> TRMF_GRAMX_LONG_SIG;
+#define TRMF_UNIT_SPLIT(X)                                                                                                   \
+    TRMF_FSOLVE_LONG_ONE(X, 1, 8) TRMF_FSOLVE_LONG_ONE(X, 1, 16) TRMF_FSOLVE_LONG_ONE(X, 2, 24) TRMF_FSOLVE_LONG_ONE(X, 2, 32) \
+    TRMF_FSOLVE_LONG_ONE(X, 3, 40) TRMF_FSOLVE_LONG_ONE(X, 3, 48) TRMF_FSOLVE_LONG_ONE(X, 4, 56) TRMF_FSOLVE_LONG_ONE(X, 4, 64) \
+    TRMF_SPLIT_NT(X, 1) TRMF_SPLIT_NT(X, 2) TRMF_SPLIT_NT(X, 3) TRMF_SPLIT_NT(X, 4)
 #define TRMF_GRAMX_NT(X, NT)                                     \
     X void gram_x_kernel<NT, true, true> TRMF_GRAMX_SIG;         \
     X void gram_x_kernel<NT, true, false> TRMF_GRAMX_SIG;        \

@@ -364,7 +364,31 @@ struct TrmfSessionImpl : SessionXPhase {
         }
         if (decide_cg_shard()) return kFail;
         init_x_forms();
-        return 0;
+        return setup_split_rows();
+    }
+    // Long rows of both orientations (session_state.hpp "split rows"): lists, items and the slab of partial Grams.  Observed-entries
+    // path with the register-tiled kernels only: the full-observation path has one shared Gram, the generic kernels (rank > 64) already
+    // give a row a whole workgroup.
+    int setup_split_rows() {
+        longF.clear(); longX.clear();
+        part_slab.release(); part_stride = 0;
+        if (dense || full || generic) return 0;
+        hipDeviceProp_t prop;
+        int dev = 0;
+        TRMF_HIP_CHECK(hipGetDevice(&dev));
+        TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        const int waves = std::max(1, prop.multiProcessorCount) * 12;        // three wavefronts per SIMD: what the Gram kernels are built for
+        if (build_long_rows(longF, host_col_ptr, (size_t)n, sizeof(real) == 4 ? 512u : 2048u, waves) ||
+            build_long_rows(longX, host_row_ptr, (size_t)T, 2048u, waves)) return kFail;
+        const uint32_t items = std::max(longF.nitems, longX.nitems);
+        if (!items) return 0;
+        switch (NT) {
+            case 1: part_stride = split_part_reals<1>(true); break;
+            case 2: part_stride = split_part_reals<2>(true); break;
+            case 3: part_stride = split_part_reals<3>(true); break;
+            default: part_stride = split_part_reals<4>(true); break;
+        }
+        return part_slab.alloc((size_t)items * part_stride, false);
     }
     int set_series_transform(const real *a, const real *b) {
         if (!dense) { set_error("set_series_transform: needs a dense Y (missing == 0)"); return kFail; }
@@ -565,7 +589,16 @@ struct TrmfSessionImpl : SessionXPhase {
         return 0;
     }
     // what this session runs, in one line (trmf_session_describe; bench.py's config.parallelism)
-    std::string describe() const {
+    // which rows are cut into items (session_state.hpp "split rows"); empty when none are
+    std::string describe_split() const {
+        if (!longF.any() && !longX.any()) return "";
+        char t[224];
+        snprintf(t, sizeof t, "; split rows: F %zu rows in %u items (>= %u entries), X %zu rows in %u items (>= %u entries)", longF.rows.size(), longF.nitems,
+                 longF.thresh, longX.rows.size(), longX.nitems, longX.thresh);
+        return t;
+    }
+    std::string describe() const { return describe_forms() + describe_split(); }
+    std::string describe_forms() const {
         char buf[640];
         if (comm->world <= 1) {
             snprintf(buf, sizeof buf, "1 rank; X-solve %s", generic ? "unfused; generic kernels for rank > 64 (Gram build, F-solve)"

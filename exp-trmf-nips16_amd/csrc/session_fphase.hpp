@@ -8,12 +8,28 @@ namespace trmf {
 
 struct SessionFPhase : SessionTransport {
     // ---- F-solve (trmf.cpp:654-663 -> 369-397) -------------------------------------------------------
+    // ---- split rows: partial Grams of the items of the long rows in [rb, re) of one orientation (gram_kernels.hpp "split rows") ----
+    template <int NT_, bool PAD_> void launch_gram_part(const LongRows &L, uint32_t lo, uint32_t hi, const uint32_t *idx, const real *val,
+                                                        const real *X, uint32_t zero_row) {
+        const uint32_t i0 = L.first[lo], i1 = L.first[hi];
+        if (i1 > i0)
+            hipLaunchKernelGGL((gram_part_kernel<NT_, PAD_>), dim3((i1 - i0 + 3) / 4), dim3(256), 0, stream, idx, val, X, L.d_items.p, i0, i1,
+                               part_slab.p, part_stride, zero_row);
+    }
     template <int NT_, int KMAX_> int launch_fsolve_mfma(uint32_t rb, uint32_t re) {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
 #if !defined(TRMF_F32)
+        if (longF.any()) {
+            uint32_t lo, hi;
+            longF.range(rb, re, lo, hi);
+            if (hi > lo) {
+                launch_gram_part<NT_, false>(longF, lo, hi, Yc_idx.p, Yc_val.p, W.p, (uint32_t)T);
+                hipLaunchKernelGGL((fsolve_mfma_long_kernel<NT_, KMAX_>), dim3((hi - lo + 3) / 4), dim3(256), 0, stream, split_view(longF, lo, hi), H.p, k, (real)lambdaI);
+            }
+        }
         hipLaunchKernelGGL((fsolve_mfma_kernel<NT_, KMAX_>), dim3((rows + 3) / 4), dim3(256), 0, stream,
-                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T);
+                           Yc_ptr.p, Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T, longF.thresh - 1u);
 #endif
         return 0;
     }
@@ -21,10 +37,18 @@ struct SessionFPhase : SessionTransport {
         const uint32_t rows = re - rb;
         if (rows == 0) return 0;
 #if defined(TRMF_F32)
+        if (longF.any()) {
+            uint32_t lo, hi;
+            longF.range(rb, re, lo, hi);
+            if (hi > lo) {
+                launch_gram_part<NT_, (KMAX_ <= kTile * NT_ - 8)>(longF, lo, hi, Yc_idx.p, Yc_val.p, W.p, (uint32_t)T);
+                hipLaunchKernelGGL((fsolve_quad_long_kernel<NT_, KMAX_>), dim3((hi - lo + 15) / 16), dim3(256), 0, stream, split_view(longF, lo, hi), H.p, k, (real)lambdaI);
+            }
+        }
         const dim3 grid((rows + 15) / 16), block(256);
 #define TRMF_LAUNCH_QUAD(ABL)                                                                          \
         hipLaunchKernelGGL((fsolve_quad_kernel<NT_, KMAX_, ABL>), grid, block, 0, stream, Yc_ptr.p,    \
-                           Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T)
+                           Yc_idx.p, Yc_val.p, W.p, H.p, rb, re, k, (real)lambdaI, (uint32_t)T, longF.thresh - 1u)
 #if defined(TRMF_ABLATION)
         if (NT_ == 3 && KMAX_ == 40 && dbg_flags) {
             switch (dbg_flags) {

@@ -14,6 +14,7 @@
 //   CG     g, s, r/r1, d0/d1, Hd/Hd1, w_new, arbase: T x KP each; partial-sum arrays
 #pragma once
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -308,6 +309,58 @@ struct SessionState {
     // one grouped exchange of the time-sharded unfused CG: edge rows of nvec vectors + this rank's slots of partial arrays
     // (kind 0: apply_kernel's slots, 1: ar_tile_kernel's, 2: wnew_kernel's)
     struct PartialRef { int slot, kind; };
+
+    // ---- split rows (round 6; gram_kernels.hpp "split rows") ------------------------------------------------------------------
+    // The row kernels map rows to wavefronts statically (four item rows / one timestamp per wavefront); the reference schedules rows
+    // dynamically (trmf.cpp:371, :234,252,273) and has no cliff at a long row.  Per orientation, rows of at least `thresh` entries are
+    // cut into items of `chunk` consecutive entries (a row of more than 256 chunks: into 256 equal items), processed one item per
+    // wavefront, and their partial Grams summed in item order.  thresh: what a wavefront slot would carry if the whole orientation
+    // were spread evenly over 8 rounds of the chip's resident wavefronts -- never below the length where the row kernels are still
+    // balanced by the hardware's workgroup dispatch (512 entries for the fp32 F-solve's four rows per wavefront, 2048 for the
+    // one-row-per-wavefront kernels), so BASELINE's uniform workloads (rows of ~100 / ~1000 entries) never take this path and keep
+    // their results bit for bit.  TRMF_TEST + TRMF_LONG_ROW=<entries> (0: never) / TRMF_LONG_CHUNK=<entries> force the geometry.
+    struct LongRows {
+        uint32_t thresh = 0xffffffffu, chunk = 1024;
+        std::vector<uint32_t> rows, first;    // host copies: ids of the long rows (ascending), first item of each (+ one past the last)
+        DevBuf<uint32_t> d_rows, d_first, d_items;   // d_items: (begin, end) entry positions per item
+        uint32_t nitems = 0;
+        uint64_t nnz_long = 0;
+        bool any() const { return !rows.empty(); }
+        void clear() { thresh = 0xffffffffu; rows.clear(); first.clear(); nitems = 0; nnz_long = 0; d_rows.release(); d_first.release(); d_items.release(); }
+        // positions [lo, hi) of the list whose rows lie in [rb, re)
+        void range(uint32_t rb, uint32_t re, uint32_t &lo, uint32_t &hi) const {
+            lo = (uint32_t)(std::lower_bound(rows.begin(), rows.end(), rb) - rows.begin());
+            hi = (uint32_t)(std::lower_bound(rows.begin(), rows.end(), re) - rows.begin());
+        }
+    } longF, longX;
+    DevBuf<real> part_slab;                   // partial Grams of the items of ONE orientation at a time (F-solve, then X-side Gram)
+    uint32_t part_stride = 0;                 // reals per item: upper tiles in accumulator layout + the lane groups' rhs partials
+    static constexpr uint32_t kSplitMaxItemsPerRow = 256;
+    int build_long_rows(LongRows &L, const std::vector<uint64_t> &ptr, size_t nrows, uint32_t lo_entries, int resident_waves) {
+        L.rows.clear(); L.first.clear(); L.nitems = 0; L.nnz_long = 0;
+        const uint64_t total = nrows ? ptr[nrows] - ptr[0] : 0;
+        uint64_t th = (total / (8ull * (uint64_t)std::max(resident_waves, 1)) + 15) / 16 * 16;
+        th = std::min<uint64_t>(std::max<uint64_t>(th, lo_entries), 8192);
+        L.thresh = (uint32_t)th; L.chunk = std::max<uint32_t>(1024u, L.thresh);
+        if (const char *e = test_env("TRMF_LONG_ROW")) { const long v = atol(e); L.thresh = v <= 0 ? 0xffffffffu : (uint32_t)v; L.chunk = std::max<uint32_t>(16u, std::min<uint32_t>(L.chunk, (L.thresh + 15) / 16 * 16)); }
+        if (const char *e = test_env("TRMF_LONG_CHUNK")) L.chunk = std::max<uint32_t>(16u, ((uint32_t)atol(e) + 15) / 16 * 16);
+        std::vector<uint32_t> items;
+        for (size_t r = 0; r < nrows; r++) {
+            const uint64_t len = ptr[r + 1] - ptr[r];
+            if (len < L.thresh) continue;
+            const uint32_t per = std::max<uint32_t>(L.chunk, (uint32_t)(((len + kSplitMaxItemsPerRow - 1) / kSplitMaxItemsPerRow + 15) / 16 * 16));
+            L.rows.push_back((uint32_t)r); L.first.push_back(L.nitems);
+            for (uint64_t e0 = ptr[r]; e0 < ptr[r + 1]; e0 += per) {
+                items.push_back((uint32_t)e0); items.push_back((uint32_t)std::min<uint64_t>(e0 + per, ptr[r + 1]));
+                L.nitems++;
+            }
+            L.nnz_long += len;
+        }
+        L.first.push_back(L.nitems);
+        if (L.rows.empty()) { L.d_rows.release(); L.d_first.release(); L.d_items.release(); return 0; }
+        return L.d_rows.upload(L.rows.data(), L.rows.size()) || L.d_first.upload(L.first.data(), L.first.size()) || L.d_items.upload(items.data(), items.size()) ? kFail : 0;
+    }
+    SplitRows split_view(const LongRows &L, uint32_t lo, uint32_t hi) const { return SplitRows{L.d_rows.p, L.d_first.p, part_slab.p, part_stride, lo, hi}; }
 
     hipEvent_t xg1_event = nullptr;           // this iteration's PhaseEvents::xg1 (set by run())
     // Phase events of an iteration (TrmfIterStats.ms_*): seven hipEventRecords.  They are not free: each is a barrier packet between

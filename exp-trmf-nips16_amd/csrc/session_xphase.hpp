@@ -82,9 +82,18 @@ struct SessionXPhase : SessionFPhase {
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
         if (re <= rb) return;
         const dim3 grid((re - rb + 3) / 4), block(256);
+        uint32_t lo = 0, hi = 0;
+        if (longX.any()) longX.range(rb, re, lo, hi);     // split timestamps: partial Grams per item, then their sums -> G_i / b_i
+        const dim3 lgrid((hi - lo + 3) / 4);
 #define TRMF_LAUNCH_GRAM_X(PAD, PACKED)                                                                                      \
-    hipLaunchKernelGGL((gram_x_kernel<NT_, PAD, PACKED>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p, Bv.p, \
-                       rb, re, k, (uint32_t)n, xp.gstride)
+    do {                                                                                                                     \
+        if (hi > lo) {                                                                                                       \
+            launch_gram_part<NT_, PAD>(longX, lo, hi, Yr_idx.p, Yr_val.p, H.p, (uint32_t)n);                                 \
+            hipLaunchKernelGGL((gram_x_long_kernel<NT_, PAD, PACKED>), lgrid, block, 0, stream, split_view(longX, lo, hi), G.p, Bv.p, k, xp.gstride); \
+        }                                                                                                                    \
+        hipLaunchKernelGGL((gram_x_kernel<NT_, PAD, PACKED>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p, Bv.p, \
+                           rb, re, k, (uint32_t)n, xp.gstride, longX.thresh);                                                \
+    } while (0)
         if (rhs_pad_ok<NT_>(k)) {     // rhs accumulated by the MFMAs in the panel's pad columns
             if (gpacked) TRMF_LAUNCH_GRAM_X(true, true); else TRMF_LAUNCH_GRAM_X(true, false);
         } else {
