@@ -348,22 +348,47 @@ struct SplitRows {
 template <int NT> __host__ __device__ constexpr uint32_t split_part_reals(bool with_b) {
     return (uint32_t)(NT * (NT + 1) / 2) * 4u * kWave + (with_b ? (uint32_t)NT * kWave : 0u);
 }
-// st <- sum of the partials of items [i0, i1), left to right (the first addition is to an exact zero)
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
+// The sum of a split row's partials, left to right, INTO its first item's slot: one thread per 16-byte granule of a partial, the
+// items' loads in flight eight at a time.  (First form of this round: the consumer kernels summed the partials themselves, one
+// wavefront per row / per four rows with a whole partial per load round -- 158 us for the 370 x 21 partials of the `imp` workload,
+// a chain of memory round trips; this kernel: see profiles/r06_split_rows.txt.)  Same additions in the same order.
+__global__ __launch_bounds__(256) void split_reduce_kernel(const uint32_t *__restrict__ first, real *__restrict__ slab, uint32_t stride,
+                                                           uint32_t begin, uint32_t end, uint32_t blocks_per_row) {
+    typedef real gran_t __attribute__((ext_vector_type(16 / sizeof(real))));
+    constexpr uint32_t GR = 16 / sizeof(real);
+    const uint32_t li = begin + blockIdx.x / blocks_per_row;
+    if (li >= end) return;
+    const uint32_t i0 = first[li], i1 = first[li + 1];
+    const uint32_t gidx = (blockIdx.x % blocks_per_row) * 256u + threadIdx.x;
+    if (i1 - i0 < 2u || gidx * GR >= stride) return;
+    real *dst = slab + (size_t)i0 * stride + (size_t)gidx * GR;
+    gran_t acc = *reinterpret_cast<const gran_t *>(dst);
+    const real *p = dst + stride;
+    uint32_t it = i0 + 1;
+    for (; it + 8 <= i1; it += 8, p += (size_t)8 * stride) {
+        gran_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const gran_t *>(p + (size_t)u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += v[u];
+    }
+    for (; it < i1; it++, p += stride) acc += *reinterpret_cast<const gran_t *>(p);
+    *reinterpret_cast<gran_t *>(dst) = acc;
+}
+#endif
+
+// st <- the summed partial of a split row (slot of its first item, after split_reduce_kernel)
 template <int NT, bool WITH_B>
-__device__ __forceinline__ void sum_partials(GramState<NT> &st, const SplitRows &sp, uint32_t i0, uint32_t i1, int lane) {
+__device__ __forceinline__ void load_row_sum(GramState<NT> &st, const SplitRows &sp, uint32_t i0, int lane) {
     typedef typename Mfma16<real>::acc_t acc_t;
     constexpr int NTT = NT * (NT + 1) / 2;
-    st.clear();
-    const real *p = sp.slab + (size_t)i0 * sp.stride + 4 * lane;
-#pragma unroll 2
-    for (uint32_t it = i0; it < i1; it++, p += sp.stride) {
+    const real *p = sp.slab + (size_t)i0 * sp.stride;
 #pragma unroll
-        for (int t = 0; t < NTT; t++) st.acc[t] += *reinterpret_cast<const acc_t *>(p + t * 4 * kWave);
-        if constexpr (WITH_B) {
+    for (int t = 0; t < NTT; t++) st.acc[t] = *reinterpret_cast<const acc_t *>(p + t * 4 * kWave + 4 * lane);
 #pragma unroll
-            for (int q = 0; q < NT; q++) st.b[q] += p[NTT * 4 * kWave - 3 * lane + q * kWave];
-        }
-    }
+    for (int q = 0; q < NT; q++) st.b[q] = WITH_B ? p[NTT * 4 * kWave + q * kWave + lane] : real(0);
+    st.loss = 0;
 }
 
 #if !defined(TRMF_F32)
@@ -474,8 +499,7 @@ __device__ __forceinline__ void fsolve_mfma_body(const uint32_t *__restrict__ pt
         const uint32_t li = sp.begin + blockIdx.x * 4u + (uint32_t)wave;
         if (li >= sp.end) return;                       // wave-uniform; no block barrier below
         row = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.rows[li]);
-        sum_partials<NT, true>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]),
-                               (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li + 1]), lane);
+        load_row_sum<NT, true>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]), lane);
     } else {
         row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
         if (row >= row_end) return;                     // wave-uniform; no block barrier below
@@ -823,7 +847,7 @@ template <int NT, int KMAX>
 __global__ void fsolve_quad_long_kernel(SplitRows sp, float *__restrict__ F, int k, float lambda);
 #else
 // LONG: four SPLIT rows per wavefront (positions 4 q .. 4 q + 3 of the long-row list): each system is the sum of its row's partials
-// (sum_partials) instead of a stream of entries; finalisation, factorisation and substitutions are the same code.
+// (split_reduce_kernel -> load_row_sum) instead of a stream of entries; finalisation, factorisation and substitutions are the same code.
 template <int NT, int KMAX, int ABL, bool LONG>
 __device__ __forceinline__ void fsolve_quad_body(const uint32_t *__restrict__ ptr,
                                                           const uint32_t *__restrict__ idx,
@@ -916,7 +940,7 @@ __device__ __forceinline__ void fsolve_quad_body(const uint32_t *__restrict__ pt
     if constexpr (LONG) {
         for (int sys = 0; sys < 4; sys++) {             // wave-uniform: item ranges of positions past the list's end are empty
             if (stream.row_ptr_at(sys + 1) == stream.row_ptr_at(sys)) continue;
-            sum_partials<NT, !PAD>(st, sp, stream.row_ptr_at(sys), stream.row_ptr_at(sys + 1), lane);
+            load_row_sum<NT, !PAD>(st, sp, stream.row_ptr_at(sys), lane);
             finalize(sys);
         }
     } else if constexpr (!(ABL & 1)) {
@@ -1030,8 +1054,7 @@ __device__ __forceinline__ void gram_x_body(const uint32_t *__restrict__ ptr,
         const uint32_t li = sp.begin + blockIdx.x * 4u + (uint32_t)wave;
         if (li >= sp.end) return;                       // wave-uniform; no block barrier below
         row = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.rows[li]);
-        sum_partials<NT, !RHS_PAD>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]),
-                                   (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li + 1]), lane);
+        load_row_sum<NT, !RHS_PAD>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]), lane);
     } else {
     row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
     if (row >= row_end) return;                         // wave-uniform; no block barrier below

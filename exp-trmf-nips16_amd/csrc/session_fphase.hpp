@@ -12,9 +12,14 @@ struct SessionFPhase : SessionTransport {
     template <int NT_, bool PAD_> void launch_gram_part(const LongRows &L, uint32_t lo, uint32_t hi, const uint32_t *idx, const real *val,
                                                         const real *X, uint32_t zero_row) {
         const uint32_t i0 = L.first[lo], i1 = L.first[hi];
-        if (i1 > i0)
-            hipLaunchKernelGGL((gram_part_kernel<NT_, PAD_>), dim3((i1 - i0 + 3) / 4), dim3(256), 0, stream, idx, val, X, L.d_items.p, i0, i1,
-                               part_slab.p, part_stride, zero_row);
+        if (i1 <= i0) return;
+        hipLaunchKernelGGL((gram_part_kernel<NT_, PAD_>), dim3((i1 - i0 + 3) / 4), dim3(256), 0, stream, idx, val, X, L.d_items.p, i0, i1,
+                           part_slab.p, part_stride, zero_row);
+        // each row's partials summed into its first item's slot (rows of one item: nothing to do -- the launch is skipped when all are)
+        if (i1 - i0 > hi - lo) {
+            const uint32_t bpr = (uint32_t)((part_stride * sizeof(real) / 16 + 255) / 256);
+            hipLaunchKernelGGL(split_reduce_kernel, dim3(bpr * (hi - lo)), dim3(256), 0, stream, L.d_first.p, part_slab.p, part_stride, lo, hi, bpr);
+        }
     }
     template <int NT_, int KMAX_> int launch_fsolve_mfma(uint32_t rb, uint32_t re) {
         const uint32_t rows = re - rb;

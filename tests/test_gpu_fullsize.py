@@ -106,8 +106,8 @@ def test_config3_fp64_10_iterations_vs_reference_build():
     scalar loop + LAPACK posv there) and of r^T r (a recurrence here, recomputed there: rf_tron.h:492) are amplified.  Measured:
     1.7e-8.  The yardstick is the reference's own line-by-line restatement run beside it over the same horizon: it lands 2.6e-9 from
     the reference on 256 OpenMP threads and 1.1e-7 on 64 -- the order of its dot-product reductions alone moves the ten-iteration
-    objective by that much (printed, not gated); the two fp32 builds are 1e-4 apart there.  Gate: 1e-7.  Printed, not gated: how far the fp32 GPU run and the fp32 reference run are from that common fp64
-    trajectory after the same ten iterations."""
+    objective by that much (printed, not gated); the two fp32 builds are 1e-4 apart there.  Gate: 1e-7.  Gated as well (round 6): the fp32 GPU run is no farther from that common fp64
+    trajectory than twice the farthest of the reference side's own fp32 runs (its fp32 build on 8 and 64 threads, its fp32 restatement)."""
     import re
     from helpers import capture_fds
     if O.ref(np.float64) is None:
@@ -137,20 +137,37 @@ def test_config3_fp64_10_iterations_vs_reference_build():
     assert abs(Jg - Jr) / Jr < 1e-7
     assert relmax(model.W, W) < 1e-6 and relmax(model.H, H) < 1e-6 and relmax(model.lag_val, Th) < 1e-6
     assert len(cg_ref) == iters and cg_gpu == cg_ref
-    # the fp32 runs against this fp64 trajectory (printed only: the noise floor of the truncated fp32 CG, not an implementation error)
+    # north_star's fp32 gate -- objective 1e-5 after TEN iterations -- at this size, as a tested statement about the reference itself
+    # (VERDICT r5 item 3): the fp32 GPU run against this fp64 trajectory next to the reference's own fp32 build (8 and 64 OpenMP
+    # threads: its BLAS dot products are order dependent, so the two differ) and its fp32 restatement.  The GPU must be no farther
+    # from the fp64 trajectory than TWICE the farthest reference-side fp32 run, in objective, W and H; and where the reference's two
+    # thread counts agree with each other to 1e-5 the GPU must meet 1e-5 against them as well.
     Y32 = Y.astype(np.float32)
-    W32, H32, T32 = m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32))
-    g32 = make_model(W32, H32, T32, lags)
+    g32 = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), lags)
     with session.Session(Y32, g32, missing=True, **synth.HYPER) as s:
         s.run(iters); s.download()
-    line = 'config 3 after 10 iterations, distance to the fp64 trajectory (objective rel / relfro W / relfro H): fp32 GPU %.2e / %.2e / %.2e' % (
-        abs(O.objective(Y, lags, g32.W, g32.H, g32.lag_val, synth.HYPER) - Jr) / Jr, relfro(g32.W, W), relfro(g32.H, H))
+    Jg32 = O.objective(Y, lags, g32.W, g32.H, g32.lag_val, synth.HYPER)
+    got = dict(J=abs(Jg32 - Jr) / Jr, W=relfro(g32.W, W), H=relfro(g32.H, H))
+    side = []
+    runs = [('restatement fp32, %d threads' % min(64, NCPU), lambda a, b, c: O.train_port(Y32, lags, a, b, c, synth.HYPER, max_iter=iters, threads=min(64, NCPU)))]
     if O.ref(np.float32) is not None:
-        O.train_ref(Y32, lags, W32, H32, T32, synth.HYPER, max_iter=iters, threads=threads)
-        line += '; fp32 reference %.2e / %.2e / %.2e; fp32 GPU vs fp32 reference %.2e (objective)' % (
-            abs(O.objective(Y, lags, W32, H32, T32, synth.HYPER) - Jr) / Jr, relfro(W32, W), relfro(H32, H),
-            abs(O.objective(Y, lags, g32.W, g32.H, g32.lag_val, synth.HYPER) - O.objective(Y, lags, W32, H32, T32, synth.HYPER)) / Jr)
-    evidence(line)
+        for t in sorted({8, min(64, NCPU)}):
+            runs.append(('reference fp32 build, %d threads' % t, lambda a, b, c, t=t: O.train_ref(Y32, lags, a, b, c, synth.HYPER, max_iter=iters, threads=t)))
+    for name, fn in runs:
+        W32, H32, T32 = m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32))
+        fn(W32, H32, T32)
+        J32 = O.objective(Y, lags, W32, H32, T32, synth.HYPER)
+        side.append(dict(name=name, J=abs(J32 - Jr) / Jr, W=relfro(W32, W), H=relfro(H32, H), Jabs=J32))
+    evidence('config 3 after 10 iterations, distance to the fp64 trajectory (objective rel / relfro W / relfro H): fp32 GPU %.2e / %.2e / %.2e; %s' % (
+        got['J'], got['W'], got['H'], '; '.join('%s %.2e / %.2e / %.2e (GPU vs it, objective: %.2e)' % (r['name'], r['J'], r['W'], r['H'], abs(Jg32 - r['Jabs']) / Jr) for r in side)))
+    for key in ('J', 'W', 'H'):
+        assert got[key] <= 2.0 * max(r[key] for r in side), (key, got[key], [r[key] for r in side])
+    refs = [r for r in side if r['name'].startswith('reference')]
+    if len(refs) == 2:
+        spread = abs(refs[0]['Jabs'] - refs[1]['Jabs']) / Jr
+        evidence('config 3 after 10 iterations: the reference fp32 build against ITSELF on two thread counts: objective rel %.2e (north_star asks 1e-5 of the GPU)' % spread)
+        if spread < 1e-5:
+            assert all(abs(Jg32 - r['Jabs']) / Jr < 1e-5 for r in refs)
 
 
 def test_config5_full_size_single_gpu_vs_oracle():
