@@ -244,6 +244,12 @@ def main():
                          'window; 1 = every iteration.  The seven event records of an iteration cost 21-26 us (2.5 %% of a config-3 '
                          'iteration, 22 %% of a config-2 one): the default samples every third iteration, which alternates between '
                          'iterations with and without a Theta-solve')
+    ap.add_argument('--repeat', type=int, default=0,
+                    help='run the timed window of --steps iterations R times, every time from the SAME post-warm-up state (the session is rewound '
+                         'on the device between windows, outside the timed regions); `value` is over all windows, `windows` lists the median / '
+                         'min / max of the individual ones.  0 (default): as many windows as make the timed region >= --min-timed-s seconds '
+                         '(a 17 ms window is invisible to an external utilisation sampler); 1: a single window')
+    ap.add_argument('--min-timed-s', type=float, default=2.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'persist', 'shard'],
                     help='multi-GPU CG form (sets TRMF_CG; default: the library measures replicated vs time-sharded)')
@@ -337,16 +343,37 @@ def main():
     s = session.Session(prob['Y'], model, missing=missing, log_norms=False, timing=max(1, args.timing), **hyper)
     t_up = time.perf_counter() - t_up
     s.run(args.warmup)
-    device_sync(s); barrier()
-    t0 = time.perf_counter()
-    s.run(args.steps)
-    device_sync(s); barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
+    device_sync(s)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
         import torch
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([x], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        return float(t.item())
+
+    # The timed region: R windows of EXACTLY --steps iterations, each bracketed by a barrier + device synchronisation on both sides
+    # and each starting from the same state (mark / rewind on the device, outside the brackets) -- so every window does the same
+    # work (same CG step counts) and the windows' spread is the measurement's noise.  The maximum over ranks is taken per window.
+    if args.repeat != 1:
+        s.mark()
+    windows = []
+    repeat = max(1, args.repeat)
+    w = 0
+    while w < repeat:
+        if w > 0:
+            s.rewind()
+        device_sync(s); barrier()
+        t0 = time.perf_counter()
+        s.run(args.steps)
+        device_sync(s); barrier()
+        windows.append(max_over_ranks(time.perf_counter() - t0))
+        w += 1
+        if args.repeat == 0 and w == 1:        # auto: from the first window's time (identical on every rank after the reduction)
+            repeat = int(min(1000, max(1, -(-args.min_timed_s // max(windows[0], 1e-6)))))
+    elapsed = float(sum(windows))
+    total_steps = args.steps * len(windows)
 
     state_file = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -369,13 +396,32 @@ def main():
     if replicas_note:
         described = replicas_note + '; each: ' + described
     bytes_f = s.fsolve_bytes()
-    timed = [x for x in st if x['ms_F'] >= 0] or st        # the iterations of the window that carried phase events (--timing)
-    ms_fk = float(np.mean([x['ms_F_kernel'] for x in timed]))
-    ms_xg = float(np.mean([x['ms_X_gram'] for x in timed]))
-    ms_x = float(np.mean([x['ms_X'] for x in timed]))
+    timed = [x for x in st if x['ms_F'] >= 0]              # the iterations of the window that carried phase events (--timing)
+    have_events = bool(timed)
+    if not have_events:                                    # none did: phases / rooflines are reported as absent (null), not as averages of the -1 sentinels
+        timed = st
+    ms_fk = float(np.mean([x['ms_F_kernel'] for x in timed])) if have_events else 0.0
+    ms_xg = float(np.mean([x['ms_X_gram'] for x in timed])) if have_events else 0.0
+    ms_x = float(np.mean([x['ms_X'] for x in timed])) if have_events else 0.0
     cg_steps = float(np.mean([x['cg_iter'] for x in timed]))   # of the same iterations (us per pass = their CG time / their passes)
     s.download()
     s.close()
+
+    # SURVEY.md 8(d)'s protocol beside the driver's flags: 2 warm-up + 10 timed iterations FROM THE RANDOM START (the early iterations
+    # run their CG to the 20-step cap, later ones stop at 12-14: a different mix of work from a window after --warmup iterations)
+    survey = None
+    if world == 1:
+        m_s = synth.initial_model(prob['Y'], prob['lag_set'], cfg['k'], seed=0)
+        with session.Session(prob['Y'], m_s, missing=missing, log_norms=False, timing=0, **hyper) as s_s:
+            s_s.run(2).sync()
+            s_s.mark()
+            ts = []
+            for _ in range(5):
+                s_s.rewind()
+                t1 = time.perf_counter(); s_s.run(10).sync(); ts.append(time.perf_counter() - t1)
+            cg_s = [int(x['cg_iter']) for x in s_s.stats(10)]
+        survey = {'warmup': 2, 'steps': 10, 'from': 'the random start (Model.initialize, seed 0)', 'iter_per_s': 10.0 / float(np.median(ts)),
+                  'windows': len(ts), 'iter_per_s_min': 10.0 / max(ts), 'iter_per_s_max': 10.0 / min(ts), 'cg_iter': cg_s}
 
     if rank == 0:
         nnz = int(prob['Y'].nnz) if hasattr(prob['Y'], 'nnz') else int(prob['Y'].size)
@@ -391,9 +437,14 @@ def main():
         except (OSError, ValueError, KeyError):
             pass
         out = {
-            'metric': 'als_iterations_per_sec', 'value': args.steps / elapsed, 'unit': 'iter/s',
+            'metric': 'als_iterations_per_sec', 'value': total_steps / elapsed, 'unit': 'iter/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'ms_per_step': 1e3 * elapsed / total_steps, 'higher_is_better': True,
+            # R windows of `steps` iterations each, all from the same post-warm-up state; value = R * steps / (sum of the windows' times)
+            'value_survey_protocol': survey,
+            'windows': (lambda r: {'repeat': len(windows), 'steps_each': args.steps, 'timed_region_s': elapsed, 'iter_per_s_median': float(np.median(r)),
+                                   'iter_per_s_min': float(np.min(r)), 'iter_per_s_max': float(np.max(r)), 'spread': float((np.max(r) - np.min(r)) / np.median(r)),
+                                   'first_window_iter_per_s': float(r[0])})(np.array([args.steps / t for t in windows])),
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if dtype == np.float32 else 'f64',
             'data': 'synthetic',
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
@@ -403,9 +454,12 @@ def main():
                 # DESIGN.md section 6): F rows / X-side Gram rows sharded or replicated, the CG replicated or sharded over time with the
                 # exchange through RCCL or peer to peer -- with the slowest rank's measured X phase of every candidate
                 'parallelism': described,
-                'phases_ms_rank0': {'F': float(np.mean([x['ms_F'] for x in timed])), 'X': float(np.mean([x['ms_X'] for x in timed])),
-                                    'Theta': float(np.mean([x['ms_LV'] for x in timed]))}},
-            'roofline': {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_mfma_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8), 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
+                'phases_ms_rank0': None if not have_events else {'F': float(np.mean([x['ms_F'] for x in timed])), 'X': float(np.mean([x['ms_X'] for x in timed])),
+                                    'Theta': float(np.mean([x['ms_LV'] for x in timed]))},
+                'degraded': 'replicas' if replicas_note else None},
+            'roofline': None if not have_events else {'kernel': ('fsolve_quad_kernel' if dtype == np.float32 else 'fsolve_mfma_kernel') + '<{},{}>'.format((cfg['k'] + 15) // 16, (cfg['k'] + 7) // 8 * 8)
+                                   + (' + the split path of long rows (gram_part_kernel, split_reduce_kernel, fsolve_*_long_kernel)' if 'split rows' in described else ''),
+                         'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBPS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': bytes_f, 'avg_kernel_ms': ms_fk,
                          'byte_model': 'nnz*(4+s+k*s) + (rows+1)*8 + rows*k*s over this rank\'s item rows',
@@ -422,10 +476,10 @@ def main():
                     157.3 if dtype == np.float32 else 78.6, 155.0 if dtype == np.float32 else 50.3),
             'roofline_x': roofline_x(cfg, nnz, dtype, missing, world, ms_xg, ms_x, cg_steps, described),
             'one_shot': one_shot,
-            'phases_ms': {'F': float(np.mean([x['ms_F'] for x in timed])), 'X': float(np.mean([x['ms_X'] for x in timed])),
-                          'Theta': float(np.mean([x['ms_LV'] for x in timed])),
+            'phases_ms': {'F': float(np.mean([x['ms_F'] for x in timed])) if have_events else None, 'X': float(np.mean([x['ms_X'] for x in timed])) if have_events else None,
+                          'Theta': float(np.mean([x['ms_LV'] for x in timed])) if have_events else None,
                           'cg_iter': [int(x['cg_iter']) for x in st],
-                          'timed_iterations': len(timed), 'of': len(st),
+                          'timed_iterations': len(timed) if have_events else 0, 'of': len(st),
                           'note': 'HIP events of the iterations that carried them (every %d-th of the window; each such iteration pays seven event '
                                   'records, ~25 us, the others none -- value / ms_per_step are wall clock over ALL iterations); F / X / Theta '
                                   'overlap where the Theta-solve runs on its own stream under the next F-solve' % max(1, args.timing)},

@@ -1423,17 +1423,19 @@ __global__ __launch_bounds__(256) void accept_kernel(XParams p, XState *__restri
                                                      const real *__restrict__ w_new,
                                                      real *__restrict__ w,
                                                      XState *__restrict__ log_x, double *__restrict__ log_norms,
-                                                     size_t e_begin, size_t e_end) {
+                                                     size_t e_begin, size_t e_end, int direct) {
     __shared__ double smem[256];
     const double gs = (double)(real)sum_partials(Pbase + P_GS * (size_t)p.pstride, np, smem);
     const double sr = (double)(real)sum_partials(Pbase + P_SR * (size_t)p.pstride, np, smem);
-    const double sHs = sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem);
+    const double sHs = direct ? sum_partials(Pbase + P_DOT * (size_t)p.pstride, np_dot, smem) : 0.0;
     const double snorm = sqrt((double)(real)sum_partials(Pbase + P_SS * (size_t)p.pstride, np, smem));
     const double rho = Prr_final ? (double)(real)sum_partials(Prr_final, np, smem)
                                  : (double)(real)st->rho_hist[st->cg_iter];              // fused CG path
     const double f = st->f;
     const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190
-    const double actred = -(gs + 0.5 * sHs);                                 // = f - f(w+s), exactly
+    // direct (diagnostics): s^T H s from one more operator pass; else through the CG's recurrence r = -g - H s, i.e. s^T H s =
+    // -s^T (g + r) and f - f(w+s) = prered (cg_persist.hpp has the argument)
+    const double actred = direct ? -(gs + 0.5 * sHs) : prered;
     const double fnew = f - actred;
     const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
     if (accept) {
@@ -1545,12 +1547,13 @@ template <int NTH = 256>
 __global__ __launch_bounds__(NTH) void accept_tile_kernel(XParams p, XState *__restrict__ st, const double *__restrict__ msgP,
                                                           TileShard sh, int sharded, const real *__restrict__ w_new,
                                                           real *__restrict__ w, XState *__restrict__ log_x,
-                                                          double *__restrict__ log_norms) {
+                                                          double *__restrict__ log_norms, int direct) {
     __shared__ double smem[256];
     double gs_d = 0, sr_d = 0, ss_d = 0, sHs = 0;
     for (int i = threadIdx.x; i < sh.nbt; i += NTH) {
         const size_t ri = sharded ? rec_index<true>(sh, i) : rec_index<false>(sh, i);
-        gs_d += msgP[ri + 4]; sr_d += msgP[ri + 5]; ss_d += msgP[ri + 6]; sHs += msgP[ri + 2];
+        gs_d += msgP[ri + 4]; sr_d += msgP[ri + 5]; ss_d += msgP[ri + 6];
+        if (direct) sHs += msgP[ri + 2];
     }
     block_allsum3<NTH / 64>(gs_d, sr_d, ss_d, smem);
     sHs = block_allsum<NTH / 64>(sHs, smem);
@@ -1559,7 +1562,7 @@ __global__ __launch_bounds__(NTH) void accept_tile_kernel(XParams p, XState *__r
     const double rho = (double)(real)st->rho_hist[st->cg_iter];
     const double f = st->f;
     const double prered = -0.5 * (gs - sr);                                  // rf_tron.h:190
-    const double actred = -(gs + 0.5 * sHs);                                 // = f - f(w+s), exactly
+    const double actred = direct ? -(gs + 0.5 * sHs) : prered;               // f - f(w+s): directly / through the recurrence (accept_kernel)
     const double fnew = f - actred;
     const bool accept = actred > 1e-4 * prered;                              // eta0, rf_tron.h:222
     if (accept) {

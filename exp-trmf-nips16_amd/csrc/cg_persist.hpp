@@ -721,36 +721,44 @@ __global__ __launch_bounds__(NTH, NTH == 256 ? 2 : 1) void cg_persist_kernel(XPa
         gs += (double)gown[e] * (double)snew; sr += (double)snew * (double)rnew; ss += (double)snew * (double)snew;
     }
     block_allsum3<NW>(gs, sr, ss, smem);
-    if (tid == 0) publish(xi, gs, sr, ss, 0);
-    publish_rows(xi, sown);
+    // a.direct (diagnostics; TRMF_TEST + TRMF_CG_DIRECT): one more operator pass evaluates s^T H s and the residual -g - H s directly.
+    // Otherwise (round 6) this is the solve's LAST exchange: the CG's own recurrence r = -g - H s gives s^T H s = -s^T (g + r) -- what the
+    // reference's prered is made of (rf_tron.h:189-190) -- so f(w + s) - f(w) = g.s + 1/2 s.Hs = 1/2 (g.s - s.r): actred = prered, one
+    // pass (~12 us at config 3) and the halo rows of s saved.  How far the recurrence is from the direct residual at the stopping
+    // step is on record (tests/test_gpu_fullsize.py, < 1e-2 of rho; the exit is at 10 % of |g|).
+    const bool direct = a.direct != 0;
+    if (tid == 0) publish(xi, gs, sr, ss, 0, !direct);
+    if (direct) publish_rows(xi, sown);
     double cs[4];
-    if (!collect(xi, 3, cs, true, vs)) return;             // + the halo rows of s (vs: the direction is no longer needed)
+    if (!collect(xi, 3, cs, direct, vs)) return;           // + the halo rows of s (vs: the direction is no longer needed)
     xi++;
     if (tid == 0) { keep[3] = cs[0]; keep[4] = cs[1]; keep[5] = cs[2]; }     // parked across the product below (registers)
 
     // =========================== H s and the acceptance test (hv_tile_kernel<HV_PLAIN>, accept_tile_kernel) ===========================
-    for (int e = tid; e < own_n; e += NTH) vs[own0 + e] = sown[e];
-    for (int e = own_n + tid; e < TI * KP; e += NTH) vs[own0 + e] = 0;     // a short last tile: rows past T
-    __syncthreads();
-    double sHs = 0, unused2 = 0, rdir = 0, unused3 = 0;
-    if (ar_on) ar_residuals(unused2);
-    __syncthreads();
-    product([&](int rr, int i, int tcol, int tpos, real x, double ac, double od) {
-        const real oc = (real)(od + ac);
-        sHs += (double)x * (double)oc;
-        // the residual of the step evaluated directly, -g - H s: the CG's own r^T r is the recurrence rho - 2 alpha <r,Hd> +
-        // alpha^2 <Hd,Hd>, and the stop test reads it (its drift against the direct norm is on record now)
-        const double rt = (double)gown[rr * KP + tpos] + (double)oc;
-        rdir += rt * rt;
-    });
-    block_allsum3<NW>(sHs, rdir, unused3, smem);
-    if (tid == 0) publish(xi, rdir, 0, sHs, 0, true);
-    double ps[4];
-    if (!collect(xi, 3, ps, false, nullptr)) return;
+    double ps[4] = {-1.0, 0, 0, 0};
+    if (direct) {
+        for (int e = tid; e < own_n; e += NTH) vs[own0 + e] = sown[e];
+        for (int e = own_n + tid; e < TI * KP; e += NTH) vs[own0 + e] = 0;     // a short last tile: rows past T
+        __syncthreads();
+        double sHs = 0, unused2 = 0, rdir = 0, unused3 = 0;
+        if (ar_on) ar_residuals(unused2);
+        __syncthreads();
+        product([&](int rr, int i, int tcol, int tpos, real x, double ac, double od) {
+            const real oc = (real)(od + ac);
+            sHs += (double)x * (double)oc;
+            // the residual of the step evaluated directly, -g - H s: the CG's own r^T r is the recurrence rho - 2 alpha <r,Hd> +
+            // alpha^2 <Hd,Hd>, and the stop test reads it (its drift against the direct norm is on record now)
+            const double rt = (double)gown[rr * KP + tpos] + (double)oc;
+            rdir += rt * rt;
+        });
+        block_allsum3<NW>(sHs, rdir, unused3, smem);
+        if (tid == 0) publish(xi, rdir, 0, sHs, 0, true);
+        if (!collect(xi, 3, ps, false, nullptr)) return;
+    } else __syncthreads();                                                      // keep[] (thread 0) before everybody reads it
     const double gsr = (double)(real)keep[3], srr = (double)(real)keep[4];       // BLAS dots in val_type (rf_tron.h:186-187)
     const double snorm = sqrt((double)(real)keep[5]);
     const double prered = -0.5 * (gsr - srr);                                    // rf_tron.h:190
-    const double actred = -(gsr + 0.5 * ps[2]);                                  // = f - f(w+s), exactly
+    const double actred = direct ? -(gsr + 0.5 * ps[2]) : prered;                // f - f(w+s): directly / through the recurrence
     const double f = keep[0], gnorm = keep[1], rho_stop = keep[2];               // (written before many barriers ago)
     const double fnew = f - actred;
     const bool accept = actred > 1e-4 * prered;                                  // eta0, rf_tron.h:222

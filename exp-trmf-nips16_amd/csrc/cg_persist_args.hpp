@@ -31,6 +31,7 @@ struct PersistArgs {
     unsigned long long *peer_hll[kMaxPeers];
     long long timeout_ticks;       // bound of every poll (100 MHz ticks; kPersistTimeoutTicks unless TRMF_PERSIST_TIMEOUT_MS says otherwise)
     long long *prof;               // -DTRMF_PERSIST_PROF builds only: cycle stamps of the phases (tile 0 and the middle tile)
+    int direct;                    // diagnostics: the closing H s pass (s^T H s and |-g - H s| evaluated directly); 0: through the CG's recurrence
     int fail_tile, fail_x;         // test hook (TRMF_TEST + TRMF_PERSIST_FAIL=tile:exchange): that tile never publishes its record of
                                    // that exchange (-2: of the final one, the acceptance test's) -- every workgroup's poll runs into its bound
 };

@@ -20,8 +20,11 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstring>
 #include <deque>
+#include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/trmf_abi.h"
@@ -48,6 +51,13 @@ struct Comm {
     // the per-step exchange of the time-sharded CG (one message slot per rank: tile records + edge rows).
     virtual int allgather_slots(void *dbuf, size_t slot_bytes, hipStream_t stream) = 0;
     virtual bool solo() const { return false; }      // SoloComm: rank r of N without peers (measurement aid)
+    // The ranks are threads of ONE process (session_group.hpp: TRMF_DEVICES behind the unchanged c_trmf_train): device pointers of
+    // a peer are valid here as they are -- same device, or another device after hipDeviceEnablePeerAccess -- so the peer-to-peer
+    // arenas are exchanged as raw pointers instead of IPC handles (which a process cannot open on itself).
+    virtual bool in_process() const { return false; }
+    virtual int device_of(int /*rank*/) const { return -1; }
+    // all ranks of an in-process group meet here (no-op elsewhere): frees of memory that peers store into are ordered behind it
+    virtual int barrier() { return 0; }
 };
 
 // ---- equal-slot staging shared by the communicators -----------------------------------------------
@@ -192,6 +202,73 @@ struct CallbackComm : Comm {
     }
 };
 
+// ---- ranks as threads of one process --------------------------------------------------------------------------------------
+// ThreadGroup: what the N rank threads of a session group share -- a reusable barrier that a failing rank can break (every
+// waiter then returns an error instead of hanging), and a table of the device pointers of the collective in flight.
+struct ThreadGroup {
+    int world = 1;
+    std::vector<int> device;                 // HIP device of every rank (duplicates allowed: virtual ranks on one device)
+    std::mutex mu;
+    std::condition_variable cv;
+    int arrived = 0;
+    unsigned long long generation = 0;
+    std::atomic<int> failed{0};
+    std::vector<void *> ptr;
+    explicit ThreadGroup(std::vector<int> devs) : world((int)devs.size()), device(std::move(devs)), ptr(world, nullptr) {}
+    void fail() { failed.store(1); std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+    int barrier() {
+        std::unique_lock<std::mutex> lk(mu);
+        if (failed.load()) return kFail;
+        const unsigned long long gen = generation;
+        if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return 0; }
+        cv.wait(lk, [&] { return generation != gen || failed.load(); });
+        return generation != gen ? 0 : kFail;
+    }
+};
+// ThreadComm: the all-gathers of comm.hpp between the rank threads of a ThreadGroup -- every rank publishes its buffer, waits for
+// the others' blocks to be complete (stream synchronisation + barrier), PULLS the other ranks' blocks with device-to-device copies
+// (peer copies between devices) and meets the others again before anybody's buffer may change.  Host-synchronous like
+// CallbackComm; the stream-ordered alternative on a real node is RcclComm per thread (session_group.hpp tries that first when
+// every rank has a device of its own).
+struct ThreadComm : Comm {
+    std::shared_ptr<ThreadGroup> grp;
+    bool in_process() const override { return true; }
+    int device_of(int r) const override { return grp->device[r]; }
+    int barrier() override {
+        if (grp->barrier()) { set_error("another rank of the in-process group failed"); return kFail; }
+        return 0;
+    }
+    int pull(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) {
+        auto bail = [&](const char *what) { grp->fail(); set_error(what); return kFail; };
+        {
+            std::lock_guard<std::mutex> lk(grp->mu);
+            grp->ptr[rank] = dbuf;
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) return bail("in-process gather: stream synchronisation failed");
+        if (barrier()) return kFail;
+        for (int r = 0; r < world; r++) {
+            if (r == rank || end[r] == begin[r]) continue;
+            unsigned char *dst = (unsigned char *)dbuf + begin[r];
+            const unsigned char *src = (const unsigned char *)grp->ptr[r] + begin[r];
+            const hipError_t e = grp->device[r] == grp->device[rank]
+                ? hipMemcpyAsync(dst, src, end[r] - begin[r], hipMemcpyDeviceToDevice, stream)
+                : hipMemcpyPeerAsync(dst, grp->device[rank], src, grp->device[r], end[r] - begin[r], stream);
+            if (e != hipSuccess) return bail("in-process gather: device-to-device copy failed");
+        }
+        if (hipStreamSynchronize(stream) != hipSuccess) return bail("in-process gather: stream synchronisation failed");
+        return barrier();
+    }
+    int allgatherv_ranges(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) override {
+        return pull(dbuf, begin, end, stream);
+    }
+    int allgather_slots(void *dbuf, size_t slot, hipStream_t stream) override {
+        if (slot == 0) return 0;
+        std::vector<uint64_t> b(world), e(world);
+        for (int r = 0; r < world; r++) { b[r] = (uint64_t)r * slot; e[r] = b[r] + slot; }
+        return pull(dbuf, b.data(), e.data(), stream);
+    }
+};
+
 // Minimal view of the RCCL C API (rccl.h), resolved at run time.
 struct RcclApi {
     typedef struct { char internal[128]; } UniqueId;
@@ -236,6 +313,13 @@ struct RcclComm : Comm {
     RcclApi::CommT comm = nullptr;
     RcclComm() { call_when_single = true; }   // keeps the RCCL call path testable on a 1-GPU box
     int device = 0;                           // HIP device the communicator was created on
+    std::shared_ptr<ThreadGroup> grp;         // set when the ranks are threads of this process (session_group.hpp)
+    bool in_process() const override { return grp != nullptr; }
+    int device_of(int r) const override { return grp ? grp->device[r] : -1; }
+    int barrier() override {
+        if (grp && grp->barrier()) { set_error("another rank of the in-process group failed"); return kFail; }
+        return 0;
+    }
     ~RcclComm() override {
         if (!comm) return;
         int prev = -1;

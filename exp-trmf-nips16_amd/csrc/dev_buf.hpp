@@ -22,6 +22,15 @@ struct FillStreamScope {
     ~FillStreamScope() { fill_stream() = prev; }
 };
 
+// Pool blocks are reused without device synchronisation (device_pool.hpp "Ordering"): code that enqueues work on LOCAL buffers
+// declares one of these AFTER them, so that on every early return -- a failed check between the enqueue and the function's own
+// synchronisation -- the stream is drained before the locals go back to the pool (hipFree used to synchronise implicitly).
+struct SyncStreamOnExit {
+    hipStream_t s;
+    explicit SyncStreamOnExit(hipStream_t st) : s(st) {}
+    ~SyncStreamOnExit() { if (s) (void)hipStreamSynchronize(s); }
+};
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0, cap = 0;       // elements in use / allocated (a buffer that shrinks or regrows within cap is reused)

@@ -34,6 +34,10 @@ namespace trmf {
 // (no session left) slabs above the cache cap (TRMF_POOL_MAX_MB, default 8192; 0 = plain hipMalloc / hipFree, no caching) or
 // fragmented over several slabs are released and the next session gets ONE slab of everything the last one needed.  reserve()
 // lets a session announce its footprint so that the first call allocates one slab.
+// A session that GROWS (append_rows: every window's buffers are larger than every free block, so each generation gets a slab of its
+// own) must not keep its earlier generations' slabs (31.6 GB in 527 slabs around 0.4 GB of live data after 200 windows):
+// wholly free slabs are returned to the runtime whenever a NEW slab is needed (no free block fits the request, or reserve() announces
+// a footprint that none can hold) -- they are evidently too small -- and before an allocation fails.
 // Ordering: a block is reused without any device synchronisation.  Safe because every user of a session's buffers is enqueued
 // on that session's stream (or follows a synchronisation of it), sessions synchronise their stream before they release, and
 // temporaries of asynchronous set-up code are kept until the set-up's final synchronisation.
@@ -49,7 +53,7 @@ public:
         if (!p) p = new DevicePool();         // lives for the process: device memory is returned by the runtime at exit
         return *p;
     }
-    struct Stats { uint64_t hip_mallocs = 0, reused = 0, live = 0, slab_bytes = 0, slabs = 0; };
+    struct Stats { uint64_t hip_mallocs = 0, reused = 0, live = 0, slab_bytes = 0, slabs = 0, live_bytes = 0, slab_frees = 0; };
 
     void *alloc(size_t bytes) {
         const size_t need = round_up(std::max<size_t>(bytes, 1));
@@ -62,6 +66,9 @@ public:
         }
         auto it = free_.lower_bound(std::make_pair(need, (unsigned char *)nullptr));      // best fit
         if (it == free_.end()) {
+            // a new slab is needed: slabs that are wholly free are evidently too small for this request -- a growing session's
+            // previous generations -- and go back to the runtime first (see the class comment)
+            if (st_.live > 0) (void)release_idle_slabs();
             const size_t want = std::max(need, std::max(hint_, (size_t)(8u << 20)));
             hint_ = 0;
             unsigned char *base = nullptr;
@@ -69,10 +76,14 @@ public:
             if (hipMalloc((void **)&base, want) != hipSuccess) {
                 (void)hipGetLastError();
                 got = need;
-                if (want == need || hipMalloc((void **)&base, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                if (want == need || hipMalloc((void **)&base, need) != hipSuccess) {
+                    // out of device memory: give back every slab nobody uses and try once more before reporting failure
+                    (void)hipGetLastError();
+                    if (release_idle_slabs() == 0 || hipMalloc((void **)&base, need) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+                }
             }
             st_.hip_mallocs++; st_.slabs++; st_.slab_bytes += got;
-            slabs_.push_back(base);
+            slabs_.push_back(base); slab_sizes_[base] = got;
             blocks_[base] = Block{got, true, base};
             it = free_.emplace(got, base).first;
         } else st_.reused++;
@@ -86,16 +97,18 @@ public:
             b.size = need;
         }
         b.free = false;
-        st_.live++;
+        st_.live++; st_.live_bytes += b.size;
         return p;
     }
     void free(void *ptr) {
         if (!ptr) return;
         std::lock_guard<std::mutex> lk(mu_);
-        st_.live--;
-        if (cap_bytes_ == 0) { (void)hipFree(ptr); return; }
+        if (cap_bytes_ == 0) { st_.live--; (void)hipFree(ptr); return; }
         auto it = blocks_.find((unsigned char *)ptr);
-        if (it == blocks_.end() || it->second.free) { if (it == blocks_.end()) (void)hipFree(ptr); return; }   // not ours (cannot happen)
+        // not ours, or released twice: the counters stay as they are (a double release used to underflow `live` and switch the
+        // consolidation at quiescence off for the rest of the process)
+        if (it == blocks_.end() || it->second.free) return;
+        st_.live--; st_.live_bytes -= it->second.size;
         it->second.free = true;
         auto nx = std::next(it);                                    // merge with the free neighbours of the same slab
         if (nx != blocks_.end() && nx->second.free && nx->second.slab == it->second.slab && it->first + it->second.size == nx->first) {
@@ -125,6 +138,7 @@ public:
         if (cap_bytes_ == 0) return;
         const size_t room = free_.empty() ? 0 : free_.rbegin()->first;
         if (st_.live == 0 && !slabs_.empty() && room < bytes) release_all();     // idle and too small: one slab of the right size instead
+        else if (room < bytes) (void)release_idle_slabs();                       // a growing session: its previous generation's slab
         if (room < bytes) hint_ = std::max(hint_, round_up(bytes));
     }
     void trim() {
@@ -146,11 +160,33 @@ private:
     static size_t round_up(size_t b) { return (b + 255) / 256 * 256; }
     void release_all() {
         for (unsigned char *s : slabs_) (void)hipFree(s);
-        slabs_.clear(); free_.clear(); blocks_.clear();
+        slabs_.clear(); slab_sizes_.clear(); free_.clear(); blocks_.clear();
         st_.slab_bytes = 0; st_.slabs = 0;
+    }
+    size_t slab_size(unsigned char *base) const { auto it = slab_sizes_.find(base); return it == slab_sizes_.end() ? 0 : it->second; }
+    // a wholly free slab (one free block spanning it) back to the runtime
+    void release_slab(unsigned char *base) {
+        auto it = blocks_.find(base);
+        if (it == blocks_.end() || !it->second.free || it->second.size != slab_size(base)) return;
+        free_.erase(std::make_pair(it->second.size, base));
+        st_.slab_bytes -= it->second.size; st_.slabs--; st_.slab_frees++;
+        blocks_.erase(it);
+        slab_sizes_.erase(base);
+        slabs_.erase(std::find(slabs_.begin(), slabs_.end(), base));
+        (void)hipFree(base);
+    }
+    size_t release_idle_slabs() {
+        size_t n = 0;
+        for (size_t i = slabs_.size(); i-- > 0;) {
+            unsigned char *base = slabs_[i];
+            auto it = blocks_.find(base);
+            if (it != blocks_.end() && it->second.free && it->second.size == slab_size(base)) { release_slab(base); n++; }
+        }
+        return n;
     }
     std::mutex mu_;
     std::vector<unsigned char *> slabs_;
+    std::map<unsigned char *, size_t> slab_sizes_;
     std::map<unsigned char *, Block> blocks_;                      // every block of every slab, by address
     std::set<std::pair<size_t, unsigned char *>> free_;            // the free ones, by size
     size_t hint_ = 0, cap_bytes_ = 0;
@@ -294,6 +330,18 @@ public:
         std::lock_guard<std::mutex> lk(stage_mu_);
         if (stage_) (void)hipHostFree(stage_);
         stage_ = nullptr; stage_cap_ = 0;
+    }
+    // the upload ring (24 MB of pinned memory) and its events; the next upload allocates them again
+    void release_ring() {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!ring_) return;
+        for (int j = 0; j < kSlots; j++) {
+            if (busy_[j]) { (void)hipEventSynchronize(ev_[j]); busy_[j] = false; }
+            if (ev_[j]) (void)hipEventDestroy(ev_[j]);
+            ev_[j] = nullptr;
+        }
+        (void)hipHostFree(ring_);
+        ring_ = nullptr;
     }
     // host copy with the stager's worker count (committing staged outputs into the caller's arrays)
     static void parallel_copy(void *dst, const void *src, size_t bytes) {

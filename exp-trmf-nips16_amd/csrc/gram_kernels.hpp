@@ -1056,7 +1056,9 @@ __device__ __forceinline__ void gram_x_body(const uint32_t *__restrict__ ptr,
         row = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.rows[li]);
         load_row_sum<NT, !RHS_PAD>(st, sp, (uint32_t)__builtin_amdgcn_readfirstlane((int)sp.first[li]), lane);
     } else {
-    row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
+    // one wavefront per timestamp; a workgroup is 4 wavefronts, or ONE where the rows' lengths differ widely (session_xphase.hpp:
+    // a workgroup's wavefront slots are released together, so three short rows would wait for the fourth)
+    row = row_begin + blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
     if (row >= row_end) return;                         // wave-uniform; no block barrier below
     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
     const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);

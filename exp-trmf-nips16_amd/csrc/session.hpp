@@ -50,6 +50,7 @@ struct TrmfSessionImpl : SessionXPhase {
     int download_padded(const DevBuf<real> &src, real *dst, size_t rows) {
         if (rows == 0) return 0;
         DevBuf<real> raw;
+        SyncStreamOnExit drain(stream);
         const size_t N = rows * (size_t)k;
         if (raw.alloc(N, false)) return kFail;
         hipLaunchKernelGGL(factor_unpad_kernel, dim3((unsigned)std::min<size_t>(4096, (N + 255) / 256)), dim3(256), 0, stream,
@@ -82,6 +83,7 @@ struct TrmfSessionImpl : SessionXPhase {
             sf.base = sf.fallback.data();
         }
         DevBuf<real> rawW, rawH;
+        SyncStreamOnExit drain(stream);
         if (rawW.alloc((size_t)T * k, false) || rawH.alloc((size_t)n * k, false)) return kFail;
         auto unpad = [&](const DevBuf<real> &src, size_t rows, real *dst) {
             const size_t N = rows * (size_t)k;
@@ -436,6 +438,13 @@ struct TrmfSessionImpl : SessionXPhase {
         FillStreamScope fill(stream);
         TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         const int T1 = T0 + Tn;
+        {   // the grown generation of buffers in ONE slab (the pool returns the previous generation's slab once it is wholly free)
+            const int Tsave = T; const uint64_t nzsave = nnz;
+            T = T1; nnz = dense ? (uint64_t)T1 * n : nnz + Yn->nnz;
+            const size_t fp = footprint_estimate();
+            T = Tsave; nnz = nzsave;
+            DevicePool::current().reserve(fp);
+        }
         // Failure-atomic: everything new is built in locals (device buffers, host pointer arrays, sums) and swapped into
         // the session only after every allocation, copy and kernel of the step has succeeded; a failed call leaves the
         // session exactly as it was.
@@ -443,6 +452,7 @@ struct TrmfSessionImpl : SessionXPhase {
         uint64_t new_nnz = nnz;
         double new_ysq = ysq_acc;
         DevBuf<uint32_t> ptr2, idx2, cptr2, cidx2; DevBuf<real> val2, cval2, tn2, nt2, raw2, W2;
+        SyncStreamOnExit drain(stream);
         if (!dense) {
             const uint64_t nz0 = nnz, nzn = Yn->nnz, nz1 = nz0 + nzn;
             // CSR: old rows keep their place, the block's rows follow
@@ -460,6 +470,7 @@ struct TrmfSessionImpl : SessionXPhase {
             std::vector<uint32_t> np32((size_t)n + 1);
             for (int j = 0; j <= n; j++) { new_col_ptr[j] += Yn->col_ptr[j]; np32[j] = (uint32_t)new_col_ptr[j]; }
             DevBuf<uint32_t> wptr, widx; DevBuf<real> wval;
+            SyncStreamOnExit drain_block(stream);
             if (cptr2.upload(np32.data(), np32.size()) || cidx2.alloc(nz1, false) || cval2.alloc(nz1, false) ||
                 upload_ptr32(wptr, Yn->col_ptr, (size_t)n + 1) || widx.upload(Yn->row_idx, nzn) || wval.upload((const real *)Yn->val, nzn))
                 return kFail;
@@ -562,6 +573,7 @@ struct TrmfSessionImpl : SessionXPhase {
             }
         }
         DevBuf<real> W0, H0, T0;
+        SyncStreamOnExit drain(stream);
         const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;
         if (W0.alloc(nw, false) || H0.alloc(nh, false) || T0.alloc(nt, false)) return kFail;
         TRMF_HIP_CHECK(hipMemcpyAsync(W0.p, W.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
@@ -720,6 +732,31 @@ struct TrmfSessionImpl : SessionXPhase {
         TRMF_HIP_CHECK(hipMemcpyAsync(snapH.p, H.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
         if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(snapT.p, theta.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
         snap_iter = iter;
+        return 0;
+    }
+    int mark() {
+        if (sync()) return kFail;
+        const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;
+        FillStreamScope fill(stream);
+        if (markW.alloc(nw, false) || markH.alloc(nh, false) || markT.alloc(nt, false)) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(markW.p, W.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(markH.p, H.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(markT.p, theta.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
+        mark_iter = iter;
+        return 0;
+    }
+    int rewind() {
+        if (mark_iter < 0) { set_error("rewind: no mark has been set"); return kFail; }
+        const size_t nw = (size_t)(T + 1) * KP, nh = (size_t)(n + 1) * KP, nt = (size_t)nlag * k;
+        if (markW.n != nw || markH.n != nh) { set_error("rewind: the session has grown since the mark (append_rows)"); return kFail; }
+        if (sync()) return kFail;
+        TRMF_HIP_CHECK(hipMemcpyAsync(W.p, markW.p, nw * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        TRMF_HIP_CHECK(hipMemcpyAsync(H.p, markH.p, nh * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        if (nt) TRMF_HIP_CHECK(hipMemcpyAsync(theta.p, markT.p, nt * sizeof(real), hipMemcpyDeviceToDevice, stream));
+        iter = mark_iter;
+        if (snap_iter >= 0 && take_snapshot()) return kFail;       // the recovery snapshot follows the rewound state
+        TRMF_HIP_CHECK(hipStreamSynchronize(stream));
         return 0;
     }
     int persist_recover(const XState &hx) {

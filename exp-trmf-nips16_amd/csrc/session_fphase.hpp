@@ -50,6 +50,7 @@ struct SessionFPhase : SessionTransport {
                 hipLaunchKernelGGL((fsolve_quad_long_kernel<NT_, KMAX_>), dim3((hi - lo + 15) / 16), dim3(256), 0, stream, split_view(longF, lo, hi), H.p, k, (real)lambdaI);
             }
         }
+        if (longF.any()) { uint32_t lo, hi; longF.range(rb, re, lo, hi); if (hi - lo == rows) return 0; }     // every row of the range is split: nothing left for the row kernel
         const dim3 grid((rows + 15) / 16), block(256);
 #define TRMF_LAUNCH_QUAD(ABL)                                                                          \
         hipLaunchKernelGGL((fsolve_quad_kernel<NT_, KMAX_, ABL>), grid, block, 0, stream, Yc_ptr.p,    \

@@ -1,0 +1,189 @@
+// session_group.hpp -- several GPUs behind the UNCHANGED reference entry (round 6; VERDICT r5 "multi-GPU through the reference
+// boundary").  The reference's caller is one process calling trmf.train -> c_trmf_train (trmf.py:253-264, trmf.cpp:696-725); the
+// sharded solver of DESIGN.md section 6 so far needed an SPMD launch (one process per GPU, torch.distributed carrying the RCCL id).
+// Here the ranks are THREADS of the calling process:
+//
+//     TRMF_DEVICES=0,1,2,3   (or TRMF_GPUS=4: devices 0..3)       -- SURVEY.md section 5: "GPU count, device ids via environment
+//                                                                    variables so the ABI stays identical"
+//
+// makes c_trmf_train -- and trmf_session_create, so resident sessions, the rolling-window caller and bench.py follow -- build one
+// TrmfSessionImpl per listed device, each driven by a worker thread bound to that device, joined by an in-process communicator:
+// RCCL (ncclCommInitRank from every thread, one shared id) when every rank has a device of its own, else -- or when RCCL cannot be
+// set up -- ThreadComm (comm.hpp: barriers + device-to-device pulls).  A device may be listed more than once ("0,0": virtual ranks
+// on one device; how the single-GPU test box exercises the path).  The sessions are the SAME objects the SPMD launch builds: same
+// partition, same kernels, same measure-once decisions, same bit-identical-to-one-rank iterates (TRMF_TEST=1 TRMF_TILE=narrow is the
+// one-rank reference, as for tests/test_dist.py).  Every entry point of the session API runs as one task on all workers; getters
+// answer from rank 0; outputs are committed from rank 0 only after EVERY rank has finished (all-or-nothing, trmf.cpp:632-634).
+// A rank that fails breaks the group's barrier, so no other rank waits for it; the call then fails as a whole.
+#pragma once
+
+#include <functional>
+#include <thread>
+
+#include "session.hpp"
+
+namespace trmf {
+
+// the calling thread's device / communicator overrides (trmf_abi.hip consults them before the process-level ones)
+inline int &tl_device() { static thread_local int d = -1; return d; }
+inline std::shared_ptr<Comm> &tl_comm() { static thread_local std::shared_ptr<Comm> c; return c; }
+
+struct SessionGroup {
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int(int)> task;      // argument: the rank
+        bool has_task = false, done = false, quit = false;
+        int rc = 0;
+        std::string err;
+    };
+    std::shared_ptr<ThreadGroup> grp;
+    std::vector<std::unique_ptr<Worker>> workers;
+    std::vector<TrmfSessionImpl *> impl;       // owned; created and destroyed on their worker threads
+    std::vector<std::shared_ptr<Comm>> comms;
+    std::string comm_kind = "threads";
+    int world() const { return grp->world; }
+
+    explicit SessionGroup(const std::vector<int> &devices) : grp(std::make_shared<ThreadGroup>(devices)) {
+        impl.assign(devices.size(), nullptr);
+        comms.resize(devices.size());
+        for (size_t r = 0; r < devices.size(); r++) {
+            workers.emplace_back(new Worker());
+            Worker *w = workers.back().get();
+            const int rank = (int)r, dev = devices[r];
+            w->th = std::thread([this, w, rank, dev] { loop(w, rank, dev); });
+        }
+    }
+    ~SessionGroup() {
+        for (auto &w : workers) {
+            { std::lock_guard<std::mutex> lk(w->mu); w->quit = true; }
+            w->cv.notify_all();
+            if (w->th.joinable()) w->th.join();
+        }
+    }
+    void loop(Worker *w, int rank, int dev) {
+        tl_device() = dev;
+        (void)hipSetDevice(dev);
+        for (;;) {
+            std::function<int(int)> t;
+            {
+                std::unique_lock<std::mutex> lk(w->mu);
+                w->cv.wait(lk, [&] { return w->has_task || w->quit; });
+                if (w->quit && !w->has_task) return;
+                t = w->task; w->has_task = false;
+            }
+            tl_comm() = comms[rank];
+            int rc = t(rank);
+            if (rc) {
+                grp->fail();                     // nobody waits for a rank that has failed (comm.hpp: ThreadGroup::barrier)
+                w->err = trmf_last_error_text();
+            }
+            { std::lock_guard<std::mutex> lk(w->mu); w->rc = rc; w->done = true; }
+            w->cv.notify_all();
+        }
+    }
+    static std::string trmf_last_error_text();
+    // run `f(rank)` on every worker at once; returns 0 when all returned 0 (else the first failing rank's error becomes the last error)
+    int on_all(const std::function<int(int)> &f) {
+        for (auto &w : workers) {
+            { std::lock_guard<std::mutex> lk(w->mu); w->task = f; w->has_task = true; w->done = false; w->rc = 0; w->err.clear(); }
+            w->cv.notify_all();
+        }
+        int rc = 0;
+        std::string first;
+        for (auto &w : workers) {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->done; });
+            if (w->rc && !rc) { rc = w->rc; first = w->err; }
+        }
+        // ("another rank failed" is the echo on the ranks that were waiting: report the rank that failed first by itself if there is one)
+        if (rc) {
+            for (auto &w : workers) if (w->rc && w->err.find("another rank") == std::string::npos && !w->err.empty()) { first = w->err; break; }
+            set_error(first.empty() ? "a rank of the in-process group failed" : first);
+        }
+        return rc;
+    }
+    int on_rank0(const std::function<int(int)> &f) {
+        Worker *w = workers[0].get();
+        { std::lock_guard<std::mutex> lk(w->mu); w->task = f; w->has_task = true; w->done = false; w->rc = 0; w->err.clear(); }
+        w->cv.notify_all();
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return w->done; });
+        if (w->rc) set_error(w->err);
+        return w->rc;
+    }
+    // The communicator: RCCL per thread where every rank has a device of its own (stream-ordered collectives over xGMI, no host in
+    // the loop), ThreadComm otherwise.  TRMF_INPROC_COMM=threads|rccl forces one (rccl: an error if it cannot be set up).
+    int setup_comm() {
+        const int W_ = world();
+        bool distinct = true;
+        for (int a = 0; a < W_; a++) for (int b = a + 1; b < W_; b++) if (grp->device[a] == grp->device[b]) distinct = false;
+        const char *e = getenv("TRMF_INPROC_COMM");
+        const bool want_rccl = e ? e[0] == 'r' : distinct;
+        if (want_rccl && distinct && rccl_api().load()) {
+            RcclApi::UniqueId id;
+            if (rccl_api().GetUniqueId(&id) == 0) {
+                std::vector<std::shared_ptr<RcclComm>> rc(W_);
+                std::atomic<int> bad{0};
+                (void)on_all([&](int r) {          // ncclCommInitRank blocks until every rank has joined: all threads at once
+                    auto c = std::make_shared<RcclComm>();
+                    c->rank = r; c->world = W_; c->device = grp->device[r]; c->grp = grp;
+                    if (rccl_api().CommInitRank(&c->comm, W_, id, r) != 0) { c->comm = nullptr; bad.store(1); }
+                    rc[r] = c;
+                    return 0;
+                });
+                if (!bad.load()) {
+                    for (int r = 0; r < W_; r++) comms[r] = rc[r];
+                    comm_kind = "RCCL (one communicator per thread)";
+                    return 0;
+                }
+                (void)on_all([&](int r) { rc[r].reset(); return 0; });      // destroyed on the thread (and device) that made them
+            }
+        }
+        if (e && e[0] == 'r') { set_error("TRMF_INPROC_COMM=rccl: RCCL could not be set up for the listed devices"); return kFail; }
+        for (int r = 0; r < W_; r++) {
+            auto c = std::make_shared<ThreadComm>();
+            c->rank = r; c->world = W_; c->grp = grp;
+            comms[r] = c;
+        }
+        comm_kind = "threads (barriers + device-to-device pulls)";
+        return 0;
+    }
+    // destroy the sessions (on their threads; the group may already be broken -- then nobody waits for anybody)
+    void destroy_sessions() {
+        (void)on_all([&](int r) {
+            if (impl[r]) { (void)impl[r]->sync(false); delete impl[r]; impl[r] = nullptr; }
+            return 0;
+        });
+        (void)on_all([&](int r) { comms[r].reset(); tl_comm().reset(); return 0; });
+    }
+};
+
+// "0,1,2" / TRMF_GPUS=N -> device list; empty when the variables are absent, name one device, or a communicator of the SPMD launch
+// is active (the process is already one rank of several)
+inline std::vector<int> inproc_devices(std::string *why) {
+    std::vector<int> d;
+    if (const char *e = getenv("TRMF_DEVICES")) {
+        const char *p = e;
+        while (*p) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) { if (why) *why = std::string("TRMF_DEVICES: cannot parse '") + e + "'"; return {}; }
+            d.push_back((int)v);
+            p = end;
+            while (*p == ',' || *p == ' ') p++;
+        }
+    } else if (const char *g = getenv("TRMF_GPUS")) {
+        const int nn = atoi(g);
+        for (int i = 0; i < nn; i++) d.push_back(i);
+    }
+    if (d.size() <= 1) return {};
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess) cnt = 0;
+    for (int v : d) if (v < 0 || v >= cnt) { if (why) *why = "TRMF_DEVICES names device " + std::to_string(v) + " but " + std::to_string(cnt) + " are visible"; return {}; }
+    if ((int)d.size() > kMaxWorld) { if (why) *why = "TRMF_DEVICES lists more than 64 ranks"; return {}; }
+    return d;
+}
+
+}  // namespace trmf

@@ -14,6 +14,10 @@ struct SessionTransport : SessionState {
         if (!p2p.loopback) for (void *q : p2p.peer) if (q) (void)hipIpcCloseMemHandle(q);
         p2p.loopback = false;
         p2p.peer.clear();
+        // ranks as threads of one process: the peers hold RAW pointers into this arena; nobody frees before everybody's queued work
+        // (which may still store into a peer) has drained -- every rank comes through here at the same point of the set-up / teardown
+        // (every rank, whether or not its own allocation succeeded: the barrier is the group's)
+        if (comm && comm->in_process() && comm->world > 1) { if (stream) (void)hipStreamSynchronize(stream); (void)comm->barrier(); }
         if (p2p.arena) (void)hipFree(p2p.arena);
         p2p.arena = nullptr; p2p.on = false; p2p_use = false; pbase_override = nullptr;
         for (int m = 0; m < 3; m++) p2p.msg[m] = nullptr;
@@ -102,8 +106,11 @@ struct SessionTransport : SessionState {
         if (ok) {
             ok = hipMemsetAsync(p2p.arena, 0, p2p.bytes, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess;
             hipIpcMemHandle_t h;
-            ok = ok && !p2p_forced_failure("export") && hipIpcGetMemHandle(&h, p2p.arena) == hipSuccess;
-            if (ok) std::memcpy(mine, &h, sizeof h); else (void)hipGetLastError();
+            const bool inproc = comm->in_process();          // threads of one process: the pointer itself travels (comm.hpp)
+            ok = ok && !p2p_forced_failure("export") && (inproc || hipIpcGetMemHandle(&h, p2p.arena) == hipSuccess);
+            if (ok && inproc) std::memcpy(mine, &p2p.arena, sizeof(void *));
+            else if (ok) std::memcpy(mine, &h, sizeof h);
+            else (void)hipGetLastError();
         }
         mine[64] = ok ? 1 : 0;
         int bad = -1;
@@ -116,7 +123,18 @@ struct SessionTransport : SessionState {
         ok = !p2p_forced_failure("open");
         for (int r = 0; r < W_ && ok; r++) {
             unsigned char *base = (unsigned char *)p2p.arena;
-            if (r != me) {
+            if (r != me && comm->in_process()) {
+                void *q = nullptr;
+                std::memcpy(&q, handles.data() + kSlot * r, sizeof(void *));
+                const int mydev = comm->device_of(me), rdev = comm->device_of(r);
+                if (rdev != mydev) {                        // another device of this process: direct access over xGMI
+                    const hipError_t e = hipDeviceEnablePeerAccess(rdev, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); ok = false; break; }
+                    (void)hipGetLastError();
+                }
+                p2p.peer[r] = q;
+                base = (unsigned char *)q;
+            } else if (r != me) {
                 hipIpcMemHandle_t h;
                 std::memcpy(&h, handles.data() + kSlot * r, sizeof h);
                 if (hipIpcOpenMemHandle(&p2p.peer[r], h, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); p2p.peer[r] = nullptr; ok = false; break; }
@@ -130,6 +148,7 @@ struct SessionTransport : SessionState {
         std::memset(mine, 0, sizeof mine); mine[64] = ok ? 1 : 0;
         if (agree(mine, &bad)) return kFail;          // also: nobody starts writing into a peer before every rank has opened every arena
         if (bad >= 0) return unavailable("rank " + std::to_string(bad) + " could not map a peer's arena");
+        if (comm->in_process()) p2p.loopback = true;        // raw pointers: nothing to close in release_p2p()
         if (peer_table.upload(&tab, 1)) return kFail;
         for (int m = 0; m < 3; m++) { p2p.msg[m] = tab.msg[m][me]; p2p.epoch[m] = 0; }
         // ---- stage 3: a trial exchange (flags only) with a short bound ----

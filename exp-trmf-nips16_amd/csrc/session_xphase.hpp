@@ -81,7 +81,9 @@ struct SessionXPhase : SessionFPhase {
     // ---- X-side Gram cache / loss ---------------------------------------------------------------------
     template <int NT_> void launch_gram_x(uint32_t rb, uint32_t re) {
         if (re <= rb) return;
-        const dim3 grid((re - rb + 3) / 4), block(256);
+        // skewed row lengths (session_state.hpp: LongRows::skewed): one wavefront per WORKGROUP, so that a finished row's slot is free at once
+        const uint32_t wpb = longX.skewed ? 1u : 4u;
+        const dim3 grid((re - rb + wpb - 1) / wpb), block(64 * wpb), lblock(256);
         uint32_t lo = 0, hi = 0;
         if (longX.any()) longX.range(rb, re, lo, hi);     // split timestamps: partial Grams per item, then their sums -> G_i / b_i
         const dim3 lgrid((hi - lo + 3) / 4);
@@ -89,7 +91,7 @@ struct SessionXPhase : SessionFPhase {
     do {                                                                                                                     \
         if (hi > lo) {                                                                                                       \
             launch_gram_part<NT_, PAD>(longX, lo, hi, Yr_idx.p, Yr_val.p, H.p, (uint32_t)n);                                 \
-            hipLaunchKernelGGL((gram_x_long_kernel<NT_, PAD, PACKED>), lgrid, block, 0, stream, split_view(longX, lo, hi), G.p, Bv.p, k, xp.gstride); \
+            hipLaunchKernelGGL((gram_x_long_kernel<NT_, PAD, PACKED>), lgrid, lblock, 0, stream, split_view(longX, lo, hi), G.p, Bv.p, k, xp.gstride); \
         }                                                                                                                    \
         hipLaunchKernelGGL((gram_x_kernel<NT_, PAD, PACKED>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p, Bv.p, \
                            rb, re, k, (uint32_t)n, xp.gstride, longX.thresh);                                                \
@@ -254,17 +256,20 @@ struct SessionXPhase : SessionFPhase {
         else
             hipLaunchKernelGGL(cg_close_kernel<false>, dim3(sh.ntiles), dim3(256), 0, stream, xp, xstate.p, sh, tile_TI, mc[0], mc[1], dbuf[0],
                                dbuf[1], rbuf[0], rbuf[1], hbuf[0], hbuf[1], s.p, g.p, W.p, w_new.p, mg, pt);
-        if (shard && exchange(2, -1, 1, s.p, nullptr, nullptr)) return kFail;   // halo rows of s
-        a = HvVecs{};
-        a.v = s.p; a.out = hbuf[0];
-        launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs> (fields [0..2] of the same records)
-        if (shard && exchange(2, -1, 0, nullptr, nullptr, nullptr)) return kFail;
+        // the records of the closing launch (+ under cg_direct the halo rows of s, operand of the pass below)
+        if (shard && exchange(2, -1, cg_direct ? 1 : 0, cg_direct ? s.p : nullptr, nullptr, nullptr)) return kFail;
+        if (cg_direct) {                                                           // diagnostics: s^T H s by one more operator pass (session_state.hpp)
+            a = HvVecs{};
+            a.v = s.p; a.out = hbuf[0];
+            launch_hv_tile<HV_PLAIN>(shard, a, 0, 0, nullptr, mg);                 // H s, <s,Hs> (fields [0..2] of the same records)
+            if (shard && exchange(2, -1, 0, nullptr, nullptr, nullptr)) return kFail;
+        }
         const int nb = (int)std::min<size_t>(kMaxPartials, ((size_t)(sh.row_e - sh.row_b) * KP + 255) / 256);
         if (!shard && tile_nth == 512)                 // (the records are summed in the tiles' own order: thread stride = workgroup size)
-            hipLaunchKernelGGL(accept_tile_kernel<512>, dim3(std::max(nb, 1)), dim3(512), 0, stream, xp, xstate.p, mg, sh, 0, w_new.p, W.p, log_x, log_n);
+            hipLaunchKernelGGL(accept_tile_kernel<512>, dim3(std::max(nb, 1)), dim3(512), 0, stream, xp, xstate.p, mg, sh, 0, w_new.p, W.p, log_x, log_n, cg_direct ? 1 : 0);
         else
             hipLaunchKernelGGL(accept_tile_kernel<256>, dim3(std::max(nb, 1)), dim3(256), 0, stream, xp, xstate.p, mg, sh,
-                               shard ? 1 : 0, w_new.p, W.p, log_x, log_n);
+                               shard ? 1 : 0, w_new.p, W.p, log_x, log_n, cg_direct ? 1 : 0);
         TRMF_HIP_CHECK(hipGetLastError());
         if (shard && gather_rows(W.p, tbounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return 0;
@@ -333,6 +338,7 @@ struct SessionXPhase : SessionFPhase {
         pa.timeout_ticks = kPersistTimeoutTicks;
         if (const char *e = getenv("TRMF_PERSIST_TIMEOUT_MS")) pa.timeout_ticks = std::max(1ll, atoll(e)) * 100000ll;
         pa.epoch0 = persist_epoch; pa.TI = tile_TI; pa.maxcg = maxcg; pa.log_x = log_x; pa.log_n = log_n;
+        pa.direct = cg_direct ? 1 : 0;
         pa.fail_tile = -1; pa.fail_x = -1;
         if (const char *e = test_env("TRMF_PERSIST_FAIL")) {           // "<tile>:<exchange>" (exchange -2: the final one)
             pa.fail_tile = atoi(e);
@@ -651,12 +657,14 @@ struct SessionXPhase : SessionFPhase {
         }
         hipLaunchKernelGGL(wnew_kernel, dim3(nbw), dim3(256), 0, stream, xp, st, W.p, s.p, g.p, rbuf[0], rbuf[1], w_new.p, Pb, own_b, own_e,
                            uts ? comm->rank * wn_slots : 0);
-        if (uts && uts_exchange(-1, 1, s.p, nullptr, nullptr, {{P_GS, 2}, {P_SR, 2}, {P_SS, 2}})) return kFail;
-        av = ArVecs{};
-        av.v = s.p;
-        if (hv(av, -1, 0, 0, hbuf[0], 1)) return kFail;                  // H s, <s,Hs>
+        if (uts && uts_exchange(-1, cg_direct ? 1 : 0, cg_direct ? s.p : nullptr, nullptr, nullptr, {{P_GS, 2}, {P_SR, 2}, {P_SS, 2}})) return kFail;
+        if (cg_direct) {                                                 // diagnostics: H s, <s,Hs> by one more operator application
+            av = ArVecs{};
+            av.v = s.p;
+            if (hv(av, -1, 0, 0, hbuf[0], 1)) return kFail;
+        }
         hipLaunchKernelGGL(accept_kernel, dim3(nbw), dim3(256), 0, stream, xp, st, Pb, npw, ndot, (const double *)nullptr, w_new.p,
-                           W.p, log_x, log_n, own_b, own_e);
+                           W.p, log_x, log_n, own_b, own_e, cg_direct ? 1 : 0);
         TRMF_HIP_CHECK(hipGetLastError());
         if (uts && gather_rows(W.p, ubounds, (size_t)KP * sizeof(real))) return kFail;   // the F-solve gathers rows of all of W
         return end_timed();

@@ -11,7 +11,7 @@
 #include <mutex>
 #include <random>
 
-#include "session.hpp"
+#include "session_group.hpp"
 
 namespace trmf {
 
@@ -30,7 +30,9 @@ static std::shared_ptr<Comm> g_self = std::make_shared<SelfComm>();
 static std::shared_ptr<Comm> g_comm;
 // A session shares ownership of the communicator it was created under, so trmf_dist_finalize() before
 // trmf_session_destroy() leaves the session's communicator alive until the session goes away.
-std::shared_ptr<Comm> active_comm() { return g_comm ? g_comm : g_self; }
+// (a worker thread of an in-process session group has its own communicator and device: session_group.hpp)
+std::shared_ptr<Comm> active_comm() { return tl_comm() ? tl_comm() : g_comm ? g_comm : g_self; }
+std::string SessionGroup::trmf_last_error_text() { std::lock_guard<std::mutex> lk(g_err_mu); return g_last_error; }
 
 static bool bind_device() {
     int cnt = 0;
@@ -38,7 +40,7 @@ static bool bind_device() {
         set_error("no HIP device visible (the MI355X TRMF solver has no CPU fallback)");
         return false;
     }
-    if (hipSetDevice(g_device) != hipSuccess) {
+    if (hipSetDevice(tl_device() >= 0 ? tl_device() : g_device) != hipSuccess) {
         set_error("hipSetDevice failed");
         return false;
     }
@@ -101,18 +103,65 @@ static bool validate_problem(const PyMatrix *Y, const uint32_t *lag_set, uint32_
     return true;
 }
 
-static TrmfSessionImpl *make_session(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
-                                     const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
-                                     double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
-                                     int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
-    if (!validate_problem(Y, lag_set, lag_size, W, H, LV, missing)) return nullptr;
-    if (!bind_device()) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+// one session on the calling thread's device under the calling thread's communicator (the problem has been validated)
+static TrmfSessionImpl *build_session(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
+                                      const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
+                                      double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
+                                      int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
+    if (!bind_device()) return nullptr;
     std::unique_ptr<TrmfSessionImpl> s(new TrmfSessionImpl());
     s->lambdaI = lambdaI; s->lambdaAR = lambdaAR; s->lambdaLag = lambdaLag;
     s->period_W = period_W; s->period_H = period_H; s->period_Lag = period_Lag; s->verbose = verbose;
     s->full = (missing == 0);
-    if (s->create(Y, lag_set, lag_size, W, H, LV)) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+    if (s->create(Y, lag_set, lag_size, W, H, LV)) return nullptr;
     return s.release();
+}
+
+// What a TrmfSession* points to: ONE session on the library's device -- or, under TRMF_DEVICES / TRMF_GPUS (session_group.hpp), one
+// session per listed device, each on a worker thread of this process, joined by an in-process communicator.
+struct SessionHandle {
+    TrmfSessionImpl *single = nullptr;
+    SessionGroup *group = nullptr;
+    TrmfSessionImpl *first() const { return group ? group->impl[0] : single; }
+    // f on every rank's session (one rank: on the calling thread)
+    int all(const std::function<int(TrmfSessionImpl *)> &f) const {
+        return group ? group->on_all([&](int r) { return f(group->impl[r]); }) : f(single);
+    }
+    int rank0(const std::function<int(TrmfSessionImpl *)> &f) const {
+        return group ? group->on_rank0([&](int) { return f(group->impl[0]); }) : f(single);
+    }
+    ~SessionHandle() {
+        if (group) { group->destroy_sessions(); delete group; }
+        else if (single) { (void)single->sync(false); delete single; }
+    }
+};
+
+static SessionHandle *make_session(const PyMatrix *Y, const uint32_t *lag_set, uint32_t lag_size,
+                                   const PyMatrix *W, const PyMatrix *H, const PyMatrix *LV,
+                                   double lambdaI, double lambdaAR, double lambdaLag, int32_t period_W,
+                                   int32_t period_H, int32_t period_Lag, int32_t missing, int32_t verbose) {
+    if (!validate_problem(Y, lag_set, lag_size, W, H, LV, missing)) return nullptr;
+    if (!bind_device()) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+    std::unique_ptr<SessionHandle> h(new SessionHandle());
+    std::string why;
+    const std::vector<int> devs = (g_comm || tl_comm()) ? std::vector<int>() : inproc_devices(&why);
+    if (!why.empty()) { set_error(why); fprintf(stderr, "[ERR MSG]: %s\n", why.c_str()); return nullptr; }
+    if (devs.empty()) {
+        h->single = build_session(Y, lag_set, lag_size, W, H, LV, lambdaI, lambdaAR, lambdaLag, period_W, period_H, period_Lag, missing, verbose);
+        if (!h->single) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+        return h.release();
+    }
+    h->group = new SessionGroup(devs);
+    int rc = h->group->setup_comm();
+    if (rc == 0)
+        rc = h->group->on_all([&](int r) {          // every rank uploads the whole problem to its device and builds its session
+            h->group->impl[r] = build_session(Y, lag_set, lag_size, W, H, LV, lambdaI, lambdaAR, lambdaLag, period_W, period_H, period_Lag, missing,
+                                              r == 0 ? verbose : 0);        // the reference's log lines once
+            return h->group->impl[r] ? 0 : kFail;
+        });
+    if (rc) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }    // (~SessionHandle tears the group down)
+    if (verbose) fprintf(stderr, ">> %d ranks as threads of this process on devices TRMF_DEVICES; communicator: %s\n", h->group->world(), h->group->comm_kind.c_str());
+    return h.release();
 }
 
 }  // namespace trmf
@@ -121,7 +170,7 @@ using namespace trmf;
 
 extern "C" {
 
-struct TrmfSession { TrmfSessionImpl impl; };   // opaque to callers; never instantiated as such
+struct TrmfSession { SessionHandle h; };        // opaque to callers; never instantiated as such
 
 // ------------------------------------------------------------------------------------------------
 // Section 1
@@ -181,29 +230,36 @@ void c_trmf_train(const PyMatrix *pyY, uint32_t *py_lag_set, uint32_t py_lag_siz
     const double t0 = TrmfSessionImpl::now_s();
     TrmfTrainProfile prof{};
     const DevicePool::Stats ps0 = guard.ok ? DevicePool::current().stats() : DevicePool::Stats{};
-    TrmfSessionImpl *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
-                                      lambdaLag, period_W, period_H, period_Lag, missing, verbose);
+    SessionHandle *s = make_session(pyY, py_lag_set, py_lag_size, pyW, pyH, pylag_val, lambdaI, lambdaAR,
+                                    lambdaLag, period_W, period_H, period_Lag, missing, verbose);
     if (!s) {                                        // diagnostics already on stderr; outputs untouched
         prof.failed = 1; prof.total_s = prof.setup_s = TrmfSessionImpl::now_s() - t0;
         std::lock_guard<std::mutex> lk(g_prof_mu); g_last_profile = prof; g_have_profile = true;
         return;
     }
-    s->log_norms = verbose > 0;                      // the norm lines exist only under verbose (trmf.cpp:659-688)
-    s->ev_period = 0;                                // nobody reads per-phase times of a one-shot call (they cost 21-26 us per iteration)
+    (void)s->all([&](TrmfSessionImpl *t) {
+        t->log_norms = verbose > 0;                  // the norm lines exist only under verbose (trmf.cpp:659-688)
+        t->ev_period = 0;                            // nobody reads per-phase times of a one-shot call (they cost 21-26 us per iteration)
+        return 0;
+    });
     const double t1 = TrmfSessionImpl::now_s();
-    int rc = s->run(max_iter);
-    if (rc == 0) rc = s->sync();
+    int rc = s->all([&](TrmfSessionImpl *t) { const int r = t->run(max_iter); return r ? r : t->sync(); });
     const double t2 = TrmfSessionImpl::now_s();
-    // the factors come back through host staging and are committed together: a failure anywhere leaves W, H and lag_val as
-    // the caller passed them (the reference's contract for a failed call, trmf.cpp:632-634)
-    TrmfSessionImpl::StagedFactors staged;
-    if (rc == 0) rc = s->download_staged(staged);
-    if (rc == 0) staged.commit(pyW->val, pyH->val, pylag_val->val);
-    else fprintf(stderr, "[ERR MSG]: device failure, outputs untouched: %s\n", trmf_last_error());
-    staged.lease = std::unique_lock<std::mutex>();
+    // the factors come back through host staging and are committed together: a failure anywhere -- on ANY rank -- leaves W, H and
+    // lag_val as the caller passed them (the reference's contract for a failed call, trmf.cpp:632-634).  Staged and committed on rank
+    // 0's thread (the staging lease is a mutex: locked and released by one thread); every rank holds the same factors.
+    size_t d2h = 0;
+    if (rc == 0)
+        rc = s->rank0([&](TrmfSessionImpl *t) {
+            TrmfSessionImpl::StagedFactors staged;
+            const int r = t->download_staged(staged);
+            if (r == 0) { staged.commit(pyW->val, pyH->val, pylag_val->val); d2h = staged.bW + staged.bH + staged.bL; }
+            return r;
+        });
+    if (rc) fprintf(stderr, "[ERR MSG]: device failure, outputs untouched: %s\n", trmf_last_error());
     const double t3 = TrmfSessionImpl::now_s();
-    prof.upload_s = s->t_upload_s; prof.bytes_h2d = s->bytes_uploaded;
-    prof.bytes_d2h = rc == 0 ? (double)(staged.bW + staged.bH + staged.bL) : 0.0;
+    prof.upload_s = s->first()->t_upload_s; prof.bytes_h2d = s->first()->bytes_uploaded;
+    prof.bytes_d2h = (double)d2h;
     delete s;
     const double t4 = TrmfSessionImpl::now_s();
     const DevicePool::Stats ps1 = DevicePool::current().stats();
@@ -230,6 +286,7 @@ int32_t trmf_release_cached(void) {
     DevicePool::current().trim();
     StreamCache::drop_idle();
     HostStager::current().release_staging();
+    HostStager::current().release_ring();
     return 0;
 }
 
@@ -269,78 +326,94 @@ TrmfSession *trmf_session_create(const PyMatrix *Y, const uint32_t *lag_set, uin
     return reinterpret_cast<TrmfSession *>(make_session(Y, lag_set, lag_size, W, H, lag_val, lambdaI, lambdaAR,
                                                         lambdaLag, period_W, period_H, period_Lag, missing, verbose));
 }
-#define IMPL(s) reinterpret_cast<TrmfSessionImpl *>(s)
+#define HND(s) reinterpret_cast<SessionHandle *>(s)
 
 int32_t trmf_session_run(TrmfSession *s, int32_t iters) {
     if (!s) return kFail;
     DeviceGuard guard;
-    return guard.ok ? IMPL(s)->run(iters) : kFail;
+    return guard.ok ? HND(s)->all([&](TrmfSessionImpl *t) { return t->run(iters); }) : kFail;
 }
 int32_t trmf_session_log_norms(TrmfSession *s, int32_t on) {
     if (!s) return kFail;
-    IMPL(s)->log_norms = on != 0;
-    return 0;
+    return HND(s)->all([&](TrmfSessionImpl *t) { t->log_norms = on != 0; return 0; });
 }
 int32_t trmf_session_set_timing(TrmfSession *s, int32_t period) {
     if (!s || period < 0) return kFail;
-    IMPL(s)->ev_period = period;
-    return 0;
+    return HND(s)->all([&](TrmfSessionImpl *t) { t->ev_period = period; return 0; });
 }
 int32_t trmf_session_sync(TrmfSession *s) {
     if (!s) return kFail;
     DeviceGuard guard;
-    return guard.ok ? IMPL(s)->sync() : kFail;
+    return guard.ok ? HND(s)->all([&](TrmfSessionImpl *t) { return t->sync(); }) : kFail;
+}
+int32_t trmf_session_mark(TrmfSession *s) {
+    if (!s) return kFail;
+    DeviceGuard guard;
+    return guard.ok ? HND(s)->all([&](TrmfSessionImpl *t) { return t->mark(); }) : kFail;
+}
+int32_t trmf_session_rewind(TrmfSession *s) {
+    if (!s) return kFail;
+    DeviceGuard guard;
+    return guard.ok ? HND(s)->all([&](TrmfSessionImpl *t) { return t->rewind(); }) : kFail;
 }
 int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew) {
     if (!s || !Ynew) { set_error("null session or block"); return kFail; }
     DeviceGuard guard;
-    return guard.ok ? IMPL(s)->append_rows(Ynew) : kFail;
+    return guard.ok ? HND(s)->all([&](TrmfSessionImpl *t) { return t->append_rows(Ynew); }) : kFail;
 }
-int32_t trmf_session_rows(TrmfSession *s) { return s ? IMPL(s)->T : kFail; }
+int32_t trmf_session_rows(TrmfSession *s) { return s ? HND(s)->first()->T : kFail; }
 int32_t trmf_session_set_series_transform(TrmfSession *s, const void *a, const void *b) {
     if (!s) { set_error("null session"); return kFail; }
     DeviceGuard guard;
-    return guard.ok ? IMPL(s)->set_series_transform((const real *)a, (const real *)b) : kFail;
+    return guard.ok ? HND(s)->all([&](TrmfSessionImpl *t) { return t->set_series_transform((const real *)a, (const real *)b); }) : kFail;
 }
 
 int32_t trmf_session_download(TrmfSession *s, PyMatrix *W, PyMatrix *H, PyMatrix *lag_val) {
     if (!s) return kFail;
     DeviceGuard guard;
     if (!guard.ok) return kFail;
-    TrmfSessionImpl *t = IMPL(s);
-    if (t->sync()) return kFail;
-    if (W && (W->rows != (uint64_t)t->T || W->cols != (uint64_t)t->k || W->type != TRMF_DENSE_ROWMAJOR)) { set_error("W shape/layout mismatch"); return kFail; }
-    if (H && (H->rows != (uint64_t)t->n || H->cols != (uint64_t)t->k || H->type != TRMF_DENSE_ROWMAJOR)) { set_error("H shape/layout mismatch"); return kFail; }
-    if (lag_val && (lag_val->rows != (uint64_t)t->nlag || lag_val->cols != (uint64_t)t->k || lag_val->type != TRMF_DENSE_COLMAJOR)) { set_error("lag_val shape/layout mismatch"); return kFail; }
-    if (W && t->download_padded(t->W, (real *)W->val, t->T)) return kFail;
-    if (H && t->download_padded(t->H, (real *)H->val, t->n)) return kFail;
-    if (lag_val && t->nlag)
-        TRMF_HIP_CHECK(hipMemcpy(lag_val->val, t->theta.p, sizeof(real) * (size_t)t->nlag * t->k, hipMemcpyDeviceToHost));
-    return 0;
+    if (HND(s)->all([&](TrmfSessionImpl *t) { return t->sync(); })) return kFail;       // every rank holds the same factors: rank 0 answers
+    return HND(s)->rank0([&](TrmfSessionImpl *t) -> int {
+        if (W && (W->rows != (uint64_t)t->T || W->cols != (uint64_t)t->k || W->type != TRMF_DENSE_ROWMAJOR)) { set_error("W shape/layout mismatch"); return kFail; }
+        if (H && (H->rows != (uint64_t)t->n || H->cols != (uint64_t)t->k || H->type != TRMF_DENSE_ROWMAJOR)) { set_error("H shape/layout mismatch"); return kFail; }
+        if (lag_val && (lag_val->rows != (uint64_t)t->nlag || lag_val->cols != (uint64_t)t->k || lag_val->type != TRMF_DENSE_COLMAJOR)) { set_error("lag_val shape/layout mismatch"); return kFail; }
+        if (W && t->download_padded(t->W, (real *)W->val, t->T)) return kFail;
+        if (H && t->download_padded(t->H, (real *)H->val, t->n)) return kFail;
+        if (lag_val && t->nlag)
+            TRMF_HIP_CHECK(hipMemcpy(lag_val->val, t->theta.p, sizeof(real) * (size_t)t->nlag * t->k, hipMemcpyDeviceToHost));
+        return 0;
+    });
 }
 
 int32_t trmf_session_stats(TrmfSession *s, TrmfIterStats *out, int32_t cap) {
     if (!(s && out && cap > 0)) return 0;
     DeviceGuard guard;
-    return guard.ok ? IMPL(s)->stats(out, cap) : 0;
+    if (!guard.ok) return 0;
+    if (HND(s)->group && HND(s)->all([&](TrmfSessionImpl *t) { return t->sync(); })) return 0;
+    int cnt = 0;
+    (void)HND(s)->rank0([&](TrmfSessionImpl *t) { cnt = t->stats(out, cap); return cnt < 0 ? kFail : 0; });
+    return cnt < 0 ? 0 : cnt;
 }
 double trmf_session_objective(TrmfSession *s) {
     if (!s) return NAN;
     DeviceGuard guard;
-    return guard.ok ? IMPL(s)->objective() : NAN;
+    if (!guard.ok) return NAN;
+    double J = NAN;
+    (void)HND(s)->all([&](TrmfSessionImpl *t) { const double v = t->objective(); if (t->comm->rank == 0) J = v; return 0; });
+    return J;
 }
-double trmf_session_fsolve_bytes(TrmfSession *s) { return s ? IMPL(s)->fsolve_bytes() : 0.0; }
+double trmf_session_fsolve_bytes(TrmfSession *s) { return s ? HND(s)->first()->fsolve_bytes() : 0.0; }
 int32_t trmf_session_describe(TrmfSession *s, char *buf, int32_t cap) {
     if (!s) return kFail;
-    const std::string d = IMPL(s)->describe();
+    std::string d = HND(s)->first()->describe();
+    if (HND(s)->group) d += "; ranks are threads of this process (TRMF_DEVICES), communicator: " + HND(s)->group->comm_kind;
     if (buf && cap > 0) { std::strncpy(buf, d.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
     return (int32_t)d.size();
 }
 void trmf_session_destroy(TrmfSession *s) {
     if (!s) return;
     DeviceGuard guard;
-    (void)IMPL(s)->sync(false);
-    delete IMPL(s);
+    delete HND(s);
 }
 
 // ---- multi-GPU ----------------------------------------------------------------------------------
@@ -364,7 +437,7 @@ int32_t trmf_dist_init(int32_t rank, int32_t world, const void *id_bytes) {
     RcclApi::UniqueId id;
     std::memcpy(&id, id_bytes, TRMF_UNIQUE_ID_BYTES);
     std::shared_ptr<RcclComm> c = std::make_shared<RcclComm>();
-    c->rank = rank; c->world = world; c->device = g_device;
+    c->rank = rank; c->world = world; c->device = tl_device() >= 0 ? tl_device() : g_device;
     const int rc = api.CommInitRank(&c->comm, world, id, rank);
     if (rc != 0) { set_error(std::string("ncclCommInitRank: ") + api.GetErrorString(rc)); c->comm = nullptr; return kFail; }
     g_comm = std::move(c);

@@ -59,6 +59,8 @@ def bind(lib):
     lib.trmf_session_log_norms.argtypes = [c_void_p, c_int32]; lib.trmf_session_log_norms.restype = c_int32
     lib.trmf_session_set_timing.argtypes = [c_void_p, c_int32]; lib.trmf_session_set_timing.restype = c_int32
     lib.trmf_session_sync.argtypes = [c_void_p]; lib.trmf_session_sync.restype = c_int32
+    lib.trmf_session_mark.argtypes = [c_void_p]; lib.trmf_session_mark.restype = c_int32
+    lib.trmf_session_rewind.argtypes = [c_void_p]; lib.trmf_session_rewind.restype = c_int32
     lib.trmf_session_append_rows.argtypes = [c_void_p, P]; lib.trmf_session_append_rows.restype = c_int32
     lib.trmf_session_rows.argtypes = [c_void_p]; lib.trmf_session_rows.restype = c_int32
     lib.trmf_session_set_series_transform.argtypes = [c_void_p, c_void_p, c_void_p]
@@ -124,6 +126,15 @@ class Session(object):
 
     def sync(self):
         self._check(self.lib.trmf_session_sync(self.handle), 'trmf_session_sync')
+        return self
+
+    def mark(self):
+        """Checkpoint (W, H, lag_val, iteration counter) on the device; ``rewind()`` returns to it."""
+        self._check(self.lib.trmf_session_mark(self.handle), 'trmf_session_mark')
+        return self
+
+    def rewind(self):
+        self._check(self.lib.trmf_session_rewind(self.handle), 'trmf_session_rewind')
         return self
 
     def append_rows(self, Ynew):

@@ -132,7 +132,8 @@ typedef struct {
 /* 0 and *out filled when a c_trmf_train call has completed in this process (and library), -1 otherwise. */
 TRMF_API int32_t trmf_last_train_profile(TrmfTrainProfile *out);
 /* Give back what the library keeps between calls on the selected device: pooled device memory (when no session is alive),
- * idle streams.  TRMF_POOL_MAX_MB (default 8192, 0 = keep nothing) bounds the pool.  Returns 0. */
+ * idle streams, the pinned upload ring (24 MB) and the pinned download staging.  TRMF_POOL_MAX_MB (default 8192, 0 = keep
+ * nothing) bounds the pool.  Returns 0, or -1 when the selected device cannot be made current (trmf_last_error() says why). */
 TRMF_API int32_t trmf_release_cached(void);
 
 /* sizeof(element type) of this library: 4 or 8. */
@@ -206,6 +207,11 @@ TRMF_API int32_t trmf_session_append_rows(TrmfSession *s, const PyMatrix *Ynew);
  * the 2n coefficients are uploaded.  a == NULL / b == NULL mean 1 / 0.  May be called again at any time (e.g. after
  * append_rows, with the coefficients refitted on the grown prefix). */
 TRMF_API int32_t trmf_session_set_series_transform(TrmfSession *s, const void *a /* n */, const void *b /* n */);
+/* Checkpoint of the session's (W, H, lag_val, iteration counter) ON THE DEVICE, and the way back to it: after rewind the
+ * session continues exactly as it did after mark (the solver is deterministic).  One mark per session (a new one replaces the
+ * old); append_rows invalidates it.  Both block.  No reference counterpart (bench.py repeats its timed window with these). */
+TRMF_API int32_t trmf_session_mark(TrmfSession *s);
+TRMF_API int32_t trmf_session_rewind(TrmfSession *s);
 /* Number of timestamps currently held by the session (rows of W). */
 TRMF_API int32_t trmf_session_rows(TrmfSession *s);
 /* Block until all enqueued work of the session has finished. */

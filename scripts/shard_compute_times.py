@@ -15,6 +15,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'exp-trmf-nips16_amd'))
+os.environ.setdefault('TRMF_TEST', '1')   # TRMF_FSHARD / TRMF_GRAMX below are test knobs (read only under TRMF_TEST)
 import numpy as np   # noqa: E402
 
 cfgname = sys.argv[1] if len(sys.argv) > 1 else 'c3'

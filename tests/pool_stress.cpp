@@ -53,6 +53,51 @@ int main() {
         live.clear();
         if (P.stats().live != 0) { printf("live count %llu\n", (unsigned long long)P.stats().live); return 1; }
     }
+    {
+        const auto s1 = P.stats();
+        printf("random phase: hip_mallocs %llu reused %llu slabs %llu\n", (unsigned long long)s1.hip_mallocs, (unsigned long long)s1.reused, (unsigned long long)s1.slabs);
+    }
+    {   // a session that GROWS (append_rows under the rolling-window caller): every generation's buffers are larger than every free
+        // block, the previous generation is released afterwards.  The pool must give the idle slabs back: what it holds stays within
+        // a small multiple of what is live (77x after 200 windows with the round-5 pool), and a double release must not
+        // disturb the counters.
+        P.trim();                                                   // (the random phase's slab is within the cap and would simply be reused)
+        const auto sf0 = P.stats().slab_frees;
+        std::vector<std::pair<unsigned char *, size_t>> gen;
+        size_t worst_num = 0, worst_den = 1;
+        for (int w = 0; w < 200; w++) {
+            std::vector<std::pair<unsigned char *, size_t>> next;
+            const size_t base = ((size_t)2 << 20) + (size_t)w * (64 << 10);
+            size_t total = 0;
+            for (int b = 0; b < 8; b++) total += (base * (b + 1) / 4 + 1 + 255) / 256 * 256;
+            P.reserve(total);                                       // append_rows announces the grown footprint: one slab per generation
+            for (int b = 0; b < 8; b++) {
+                const size_t n = base * (b + 1) / 4 + 1;
+                unsigned char *p = (unsigned char *)P.alloc(n);
+                if (!p) { printf("alloc failed (growing)\n"); return 1; }
+                check(p, n); live[p] = n; p[0] = 1; p[n - 1] = 2;
+                next.emplace_back(p, n);
+            }
+            for (auto &kv : gen) { P.free(kv.first); live.erase(kv.first); }
+            if (!gen.empty()) P.free(gen[0].first);                 // released twice: must be ignored
+            gen.swap(next);
+            const auto s2 = P.stats();
+            if (s2.live != gen.size()) { printf("live count %llu after a double release\n", (unsigned long long)s2.live); return 1; }
+            if (w > 4 && s2.slab_bytes * worst_den > worst_num * s2.live_bytes) { worst_num = s2.slab_bytes; worst_den = s2.live_bytes; }
+        }
+        const double ratio = (double)worst_num / (double)worst_den;
+        printf("growing session: worst slab_bytes / live_bytes %.2f, slab frees %llu\n", ratio, (unsigned long long)P.stats().slab_frees);
+        if (ratio > 4.0) { printf("pool grows without bound under a growing session\n"); return 1; }
+        if (P.stats().slab_frees - sf0 > 260) { printf("more than one slab per generation\n"); return 1; }
+        for (auto &kv : gen) { P.free(kv.first); live.erase(kv.first); }
+        if (P.stats().live != 0) { printf("live count %llu\n", (unsigned long long)P.stats().live); return 1; }
+        // back to a same-shape workload: one slab again
+        for (int round = 0; round < 3; round++) {
+            std::vector<unsigned char *> ps;
+            for (int b = 0; b < 20; b++) ps.push_back((unsigned char *)P.alloc(((size_t)1 << 20) + b * 1000));
+            for (unsigned char *p : ps) P.free(p);
+        }
+    }
     auto st = P.stats();
     printf("ok: hip_mallocs %llu reused %llu slabs %llu slab_bytes %llu live_slabs %zu\n", (unsigned long long)st.hip_mallocs, (unsigned long long)st.reused,
            (unsigned long long)st.slabs, (unsigned long long)st.slab_bytes, g_live_slabs);

@@ -21,7 +21,8 @@ pytestmark = pytest.mark.gpu
 NCPU = os.cpu_count() or 8
 
 
-def test_config3_full_size_vs_oracle():
+def test_config3_full_size_vs_oracle(monkeypatch):
+    monkeypatch.setenv('TRMF_CG_DIRECT', '1')      # diagnostics: the closing H s pass (|-g - H s| evaluated directly) -- off by default since round 6
     cfg = synth.CONFIGS['c3']
     p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=np.float32, seed=0)
     m0 = synth.initial_model(p['Y'], p['lag_set'], cfg['k'], seed=0)
