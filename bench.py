@@ -193,7 +193,7 @@ def roofline_x(cfg, nnz, dtype, missing, world, ms_xg, ms_x, cg_steps, described
         return None
     b_g, b_cg = x_byte_models(cfg, nnz, dtype.itemsize)
     ms_cg = ms_x - ms_xg
-    passes = cg_steps + 2.0            # gradient + one product per CG step + H s
+    passes = cg_steps + 1.0            # gradient + one product per CG step (the closing H s pass is gone since round 6: DESIGN.md 4.4)
     us_pass = 1e3 * ms_cg / passes
     return {'gram': {'kernel': 'gram_x_kernel', 'bound': 'hbm', 'algorithmic_bytes_per_launch': b_g, 'avg_ms': ms_xg,
                      'achieved': b_g / (ms_xg * 1e-3) / 1e9, 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': b_g / (ms_xg * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -250,6 +250,9 @@ def main():
                          'min / max of the individual ones.  0 (default): as many windows as make the timed region >= --min-timed-s seconds '
                          '(a 17 ms window is invisible to an external utilisation sampler); 1: a single window')
     ap.add_argument('--min-timed-s', type=float, default=2.0)
+    ap.add_argument('--devices', default=None,
+                    help='without a launcher: the device list of the in-process multi-GPU mode (TRMF_DEVICES; default for --gpus N: 0..N-1).  A device '
+                         'may be listed several times ("0,0": virtual ranks on one GPU -- a dry run of the multi-GPU path on a one-GPU box)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cg', default=None, choices=['replicate', 'timeshard', 'p2p', 'persist', 'shard'],
                     help='multi-GPU CG form (sets TRMF_CG; default: the library measures replicated vs time-sharded)')
@@ -272,6 +275,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus and world > 1:
         raise SystemExit('WORLD_SIZE={} but --gpus {}'.format(world, args.gpus))
+    # No launcher (WORLD_SIZE unset) and --gpus N > 1: ONE process, the ranks are threads of the library (TRMF_DEVICES; csrc/session_group.hpp)
+    # -- what a caller of the reference API gets.  Under torchrun (the driver's multi-GPU runs) every process is one rank as before.
+    inproc = 0
+    if world == 1 and (args.gpus > 1 or args.devices):
+        devs = args.devices or ','.join(str(i) for i in range(args.gpus))
+        os.environ['TRMF_DEVICES'] = devs
+        inproc = len([d for d in devs.split(',') if d.strip() != ''])
+        if args.gpus > 1 and inproc != args.gpus:
+            raise SystemExit('--devices lists {} ranks but --gpus {}'.format(inproc, args.gpus))
 
     dist = None
     replicas_note = None
@@ -356,6 +368,9 @@ def main():
     # The timed region: R windows of EXACTLY --steps iterations, each bracketed by a barrier + device synchronisation on both sides
     # and each starting from the same state (mark / rewind on the device, outside the brackets) -- so every window does the same
     # work (same CG step counts) and the windows' spread is the measurement's noise.  The maximum over ranks is taken per window.
+    can_rewind = hasattr(s.lib, 'trmf_session_mark')
+    if not can_rewind:
+        args.repeat = 1                         # a library from before round 6 (A/B runs): one window
     if args.repeat != 1:
         s.mark()
     windows = []
@@ -376,7 +391,7 @@ def main():
     total_steps = args.steps * len(windows)
 
     state_file = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not inproc and not args.no_cpu_baseline:
         # The factors the timed window started from (the CPU baseline is warm-started from the same state), reproduced AFTER the
         # timed window by a second session that repeats the warm-up from the same initial model -- the solver is deterministic (every
         # sum in a fixed order; tests/test_gpu_parity.py), so this is the state bit for bit.  Rounds 1-4 downloaded and saved it
@@ -390,6 +405,7 @@ def main():
         np.savez(state_file, W=m_w.W, H=m_w.H, lag_val=m_w.lag_val)
     one_shot = None
     if rank == 0 and world == 1 and not args.no_one_shot:
+        # (under --gpus N without a launcher this is c_trmf_train itself on N devices: every rank uploads the problem)
         one_shot = measure_one_shot(prob, cfg, hyper, missing, dtype, args.one_shot_iters)
     st = s.stats(args.steps)
     described = s.describe()          # which phases are sharded / which CG form the measure-once rule chose (set-up iterations, untimed)
@@ -410,7 +426,7 @@ def main():
     # SURVEY.md 8(d)'s protocol beside the driver's flags: 2 warm-up + 10 timed iterations FROM THE RANDOM START (the early iterations
     # run their CG to the 20-step cap, later ones stop at 12-14: a different mix of work from a window after --warmup iterations)
     survey = None
-    if world == 1:
+    if world == 1 and can_rewind:
         m_s = synth.initial_model(prob['Y'], prob['lag_set'], cfg['k'], seed=0)
         with session.Session(prob['Y'], m_s, missing=missing, log_norms=False, timing=0, **hyper) as s_s:
             s_s.run(2).sync()
@@ -432,19 +448,22 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, 'profiles', 'fsolve_traffic.json')))
             tj = tj.get(args.config, tj if tj.get('config') == args.config else {})       # one entry per configuration
-            if world == 1 and tj.get('kernel_source_sha256') == fsolve_source_digest():
+            if world == 1 and not inproc and tj.get('kernel_source_sha256') == fsolve_source_digest():
                 traffic = tj['traffic_bytes']
         except (OSError, ValueError, KeyError):
             pass
         out = {
             'metric': 'als_iterations_per_sec', 'value': total_steps / elapsed, 'unit': 'iter/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': inproc if inproc else world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / total_steps, 'higher_is_better': True,
             # R windows of `steps` iterations each, all from the same post-warm-up state; value = R * steps / (sum of the windows' times)
             'value_survey_protocol': survey,
-            'windows': (lambda r: {'repeat': len(windows), 'steps_each': args.steps, 'timed_region_s': elapsed, 'iter_per_s_median': float(np.median(r)),
-                                   'iter_per_s_min': float(np.min(r)), 'iter_per_s_max': float(np.max(r)), 'spread': float((np.max(r) - np.min(r)) / np.median(r)),
-                                   'first_window_iter_per_s': float(r[0])})(np.array([args.steps / t for t in windows])),
+            # (the first window starts at whatever clocks the warm-up left: it is listed by itself; `spread` = (max - min) / median of the others)
+            'windows': (lambda r, q: {'repeat': len(windows), 'steps_each': args.steps, 'timed_region_s': elapsed, 'iter_per_s_median': float(np.median(r)),
+                                      'iter_per_s_min': float(np.min(r)), 'iter_per_s_max': float(np.max(r)), 'spread': float((np.max(q) - np.min(q)) / np.median(q)),
+                                      'p05_p95': [float(np.percentile(q, 5)), float(np.percentile(q, 95))],
+                                      'first_window_iter_per_s': float(r[0])})(np.array([args.steps / t for t in windows]),
+                                                                               np.array([args.steps / t for t in (windows[1:] if len(windows) > 2 else windows)])),
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32' if dtype == np.float32 else 'f64',
             'data': 'synthetic',
             'config': {'workload': '{}: n={} T={} density={} nnz={} k={} |L|={} {} missing={} lambdaI={} lambdaAR={} lambdaLag={}'.format(
@@ -468,13 +487,13 @@ def main():
             # the same launch priced in arithmetic (one rank only): upper triangle of the k x k Gram + rhs per observed entry,
             # k^3/3 + 2 k^2 per system; fp64's MFMA pipe issues one v_mfma_f64_16x16x4 per ~100 cycles per SIMD on this chip
             # (profiles/r03_f64_pipe_ubench.txt) -- config 5's F-solve is bound by THAT, not by HBM
-            'roofline_compute': None if world != 1 or not missing or ms_fk <= 0 else (lambda fl, pk, pm: {
+            'roofline_compute': None if world != 1 or inproc or not missing or ms_fk <= 0 else (lambda fl, pk, pm: {
                 'kernel': 'the F-solve kernel of `roofline`', 'bound': 'mfma', 'achieved': fl / (ms_fk * 1e-3) / 1e12, 'peak': pk, 'unit': 'TFLOP/s',
                 'frac': fl / (ms_fk * 1e-3) / 1e12 / pk, 'peak_issue_rate_measured': pm, 'frac_of_measured_issue_rate': fl / (ms_fk * 1e-3) / 1e12 / pm,
                 'algorithmic_flops_per_launch': fl, 'flop_model': 'nnz*(k*(k+1) + 2*k) + rows*(k^3/3 + 2*k^2); padded MFMA tiles are not counted'})(
                     float(nnz) * (cfg['k'] * (cfg['k'] + 1) + 2 * cfg['k']) + float(cfg['n']) * (cfg['k'] ** 3 / 3.0 + 2.0 * cfg['k'] ** 2),
                     157.3 if dtype == np.float32 else 78.6, 155.0 if dtype == np.float32 else 50.3),
-            'roofline_x': roofline_x(cfg, nnz, dtype, missing, world, ms_xg, ms_x, cg_steps, described),
+            'roofline_x': roofline_x(cfg, nnz, dtype, missing, max(world, inproc), ms_xg, ms_x, cg_steps, described),
             'one_shot': one_shot,
             'phases_ms': {'F': float(np.mean([x['ms_F'] for x in timed])) if have_events else None, 'X': float(np.mean([x['ms_X'] for x in timed])) if have_events else None,
                           'Theta': float(np.mean([x['ms_LV'] for x in timed])) if have_events else None,
@@ -485,7 +504,7 @@ def main():
                                   'overlap where the Theta-solve runs on its own stream under the next F-solve' % max(1, args.timing)},
             'setup_s': {'generate': t_gen, 'upload_and_alloc': t_up},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and not inproc:
             gpu_file = None
             if state_file and missing:
                 # parity evidence at this size (untimed): the GPU repeats, from the state the timed window started from,

@@ -695,10 +695,20 @@ __global__ __launch_bounds__(256, TRMF_MFMA_WAVES) void fsolve_mfma_long_kernel(
 // The four Grams are accumulated one after the other by ONE gram_ring() stream that runs across the
 // row boundaries (the rows are adjacent in CSR), so the gather pipeline never drains inside a quad.
 
-// value of lane SRC (0..15) of the caller's own 16-lane row (ds_swizzle bit mode, no LDS memory)
+// value of lane SRC (0..15) of the caller's own 16-lane row.  Round 6: a DPP move (v_mov_b32_dpp row_newbcast:SRC, a vector-ALU
+// instruction with a few cycles of latency) instead of ds_swizzle, which travels through the LDS pipe (~100 cycles): the pivot
+// broadcast heads the dependent chain of every elimination step (broadcast -> rsq -> scale -> quad broadcast -> MFMA), 40 steps per
+// system, and with three wavefronts per SIMD that latency is not hidden (profiles/r06_fsolve_chain.txt).  Same value either way.
+#ifndef TRMF_ROW_BCAST_DPP
+#define TRMF_ROW_BCAST_DPP 1
+#endif
 template <int SRC> __device__ __forceinline__ float row_bcast(float v) {
+#if TRMF_ROW_BCAST_DPP
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + SRC, 0xf, 0xf, true));
+#else
     constexpr int pattern = (SRC << 5) | 0x10;          // and_mask = 0x10, or_mask = SRC, xor_mask = 0
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), pattern));
+#endif
 }
 
 template <int NT> __device__ __forceinline__ constexpr int quad_slab_floats() {

@@ -59,8 +59,9 @@ def bind(lib):
     lib.trmf_session_log_norms.argtypes = [c_void_p, c_int32]; lib.trmf_session_log_norms.restype = c_int32
     lib.trmf_session_set_timing.argtypes = [c_void_p, c_int32]; lib.trmf_session_set_timing.restype = c_int32
     lib.trmf_session_sync.argtypes = [c_void_p]; lib.trmf_session_sync.restype = c_int32
-    lib.trmf_session_mark.argtypes = [c_void_p]; lib.trmf_session_mark.restype = c_int32
-    lib.trmf_session_rewind.argtypes = [c_void_p]; lib.trmf_session_rewind.restype = c_int32
+    if hasattr(lib, 'trmf_session_mark'):      # (absent from libraries built before round 6: scripts/ab_builds.sh loads those side by side)
+        lib.trmf_session_mark.argtypes = [c_void_p]; lib.trmf_session_mark.restype = c_int32
+        lib.trmf_session_rewind.argtypes = [c_void_p]; lib.trmf_session_rewind.restype = c_int32
     lib.trmf_session_append_rows.argtypes = [c_void_p, P]; lib.trmf_session_append_rows.restype = c_int32
     lib.trmf_session_rows.argtypes = [c_void_p]; lib.trmf_session_rows.restype = c_int32
     lib.trmf_session_set_series_transform.argtypes = [c_void_p, c_void_p, c_void_p]

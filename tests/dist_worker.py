@@ -77,6 +77,10 @@ def gpu_host_staged(rank, world, port, out, iters, shape='small', env=None, dtyp
     res = {}
     for name in dtypes:
         dtype = np.dtype(name).type
+        if os.environ.get('TRMF_TEST_DEVICE_PER_RANK'):      # a real multi-GPU node (scripts/scale_day.sh): a device per rank
+            lib = session.lib_for(dtype)
+            if lib.trmf_set_device(rank % max(1, lib.trmf_device_count())) != 0:
+                raise RuntimeError(lib.trmf_last_error().decode())
         if shape == 'c3full':
             cfg = synth.CONFIGS['c3']
             p = synth.sparse_problem(cfg['n'], cfg['T'], cfg['k'], cfg['nlag'], cfg['density'], dtype=dtype, seed=0)

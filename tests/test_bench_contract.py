@@ -39,7 +39,7 @@ def test_x_phase_byte_models():
     assert b_cg == T * k * k * s + 6 * T * k * s == 73600000
     r = bench.roofline_x(cfg, nnz, np.dtype(np.float32), True, 1, 0.2645, 0.529, 16.0, '1 rank')
     assert abs(r['gram']['achieved'] - b_g / 0.2645e-3 / 1e9) < 1e-6 and abs(r['gram']['frac'] - r['gram']['achieved'] / 8000.0) < 1e-12
-    assert r['cg']['operator_passes_per_solve'] == 18.0 and abs(r['cg']['us_per_pass'] - 1e3 * (0.529 - 0.2645) / 18.0) < 1e-9
+    assert r['cg']['operator_passes_per_solve'] == 17.0 and abs(r['cg']['us_per_pass'] - 1e3 * (0.529 - 0.2645) / 17.0) < 1e-9
     assert bench.roofline_x(cfg, nnz, np.dtype(np.float32), True, 2, 0.2, 0.5, 16.0, '') is None       # one rank only
 
 
@@ -94,3 +94,21 @@ def test_bench_falls_back_to_replicas_when_the_library_communicator_cannot_be_se
     assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
     r = json.loads(lines[0])
     assert r['value'] > 0 and 'replicas of the one-GPU solver' in r['config']['parallelism']
+    assert r['config']['degraded'] == 'replicas'          # machine-readable: value / n_gpus of this line is NOT a sharded figure
+
+
+@pytest.mark.gpu
+def test_bench_without_a_launcher_runs_the_in_process_multi_gpu_mode_and_repeats_its_window():
+    """python bench.py --gpus 2 (no torchrun): TRMF_DEVICES inside one process (here two virtual ranks on the one device), the timed
+    window repeated from the same state -- every window does the same work."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--devices', '0,0', '--steps', '4', '--warmup', '2', '--repeat', '3',
+           '--config', 'c2', '--no-cpu-baseline', '--no-one-shot']
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    lines = [l for l in res.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, res.stdout[-2000:] + res.stderr[-3000:]
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 4 and r['windows']['repeat'] == 3 and r['windows']['steps_each'] == 4
+    assert '2 ranks' in r['config']['parallelism'] and 'threads of this process' in r['config']['parallelism']
+    assert abs(r['ms_per_step'] * 4 * 3 / 1e3 - r['windows']['timed_region_s']) < 1e-9
+    assert r['value_survey_protocol']['steps'] == 10 and r['value_survey_protocol']['iter_per_s'] > 0

@@ -25,6 +25,14 @@ def _train(p, m0, dtype, iters, missing=True, hyper=synth.HYPER, periods=(1, 1, 
     return model
 
 
+def _devs(spec):
+    """'0,0,0' as written on the one-GPU test box; a device per rank where the box has them and scripts/scale_day.sh asks for it."""
+    n = len(spec.split(','))
+    if os.environ.get('TRMF_TEST_DEVICE_PER_RANK') and session.lib_for(np.float32).trmf_device_count() >= n:
+        return ','.join(str(i) for i in range(n))
+    return spec
+
+
 def _same(a, b):
     return np.array_equal(a.W, b.W) and np.array_equal(a.H, b.H) and np.array_equal(a.lag_val, b.lag_val)
 
@@ -41,7 +49,7 @@ def test_c_trmf_train_under_TRMF_DEVICES_is_bit_identical_to_one_rank(devices, s
         monkeypatch.setenv('TRMF_TILE', 'narrow')
         one = _train(p, m0, dtype, iters)
         monkeypatch.delenv('TRMF_TILE', raising=False)
-        monkeypatch.setenv('TRMF_DEVICES', devices)
+        monkeypatch.setenv('TRMF_DEVICES', _devs(devices))
         many = _train(p, m0, dtype, iters)
         assert _same(one, many), (np.dtype(dtype).name, devices)
 
@@ -63,7 +71,7 @@ def test_every_form_of_the_sharded_solver_runs_between_threads(env, monkeypatch)
     monkeypatch.setenv('TRMF_TILE', 'narrow')
     one = _train(p, m0, dtype, 3)
     monkeypatch.delenv('TRMF_TILE', raising=False)
-    monkeypatch.setenv('TRMF_DEVICES', '0,0')
+    monkeypatch.setenv('TRMF_DEVICES', _devs('0,0'))
     two = _train(p, m0, dtype, 3)
     assert _same(one, two), env
 
@@ -73,7 +81,7 @@ def test_full_observation_path_under_TRMF_DEVICES(monkeypatch):
     pd = synth.dense_problem(90, 700, 6, [1, 2, 24], dtype=np.float64, seed=13)
     m0 = synth.initial_model(pd['Y'], pd['lag_set'], 6, seed=7)
     one = _train(pd, m0, np.float64, 3, missing=False)
-    monkeypatch.setenv('TRMF_DEVICES', '0,0')
+    monkeypatch.setenv('TRMF_DEVICES', _devs('0,0'))
     two = _train(pd, m0, np.float64, 3, missing=False)
     assert _same(one, two)
 
@@ -103,7 +111,7 @@ def test_resident_session_api_under_TRMF_GPUS_style_lists(monkeypatch):
     monkeypatch.setenv('TRMF_TILE', 'narrow')
     one, J1, d1 = run()
     monkeypatch.delenv('TRMF_TILE', raising=False)
-    monkeypatch.setenv('TRMF_DEVICES', '0, 0')
+    monkeypatch.setenv('TRMF_DEVICES', _devs('0, 0'))
     two, J2, d2 = run()
     assert '2 ranks' in d2 and 'threads of this process' in d2 and '1 rank' in d1, (d1, d2)
     assert _same(one, two) and J1 == J2
@@ -130,7 +138,7 @@ def test_a_failing_rank_fails_the_call_as_a_whole(monkeypatch):
     """All-or-nothing across ranks (trmf.cpp:632-634): a failed download on rank 0 / a broken set-up stage on one rank leaves W, H,
     lag_val as passed, and no rank is left waiting for another."""
     p, m0 = _problem('small')
-    monkeypatch.setenv('TRMF_DEVICES', '0,0')
+    monkeypatch.setenv('TRMF_DEVICES', _devs('0,0'))
     monkeypatch.setenv('TRMF_FAIL_DOWNLOAD', '1')
     model = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), p['lag_set'])
     W0, H0, T0 = model.W.copy(), model.H.copy(), model.lag_val.copy()
@@ -146,7 +154,7 @@ def test_a_failing_rank_fails_the_call_as_a_whole(monkeypatch):
 def test_verbose_lines_appear_once(monkeypatch):
     """The reference's `>> iter` lines (trmf.cpp:661,672,687) come from rank 0 only."""
     p, m0 = _problem('small')
-    monkeypatch.setenv('TRMF_DEVICES', '0,0')
+    monkeypatch.setenv('TRMF_DEVICES', _devs('0,0'))
     model = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), p['lag_set'])
     with capture_fds() as cap:
         trmf.train(p['Y'].astype(np.float32), model, max_iter=2, missing=True, verbose=1, **synth.HYPER)
