@@ -18,6 +18,7 @@
 #pragma once
 
 #include <functional>
+#include <map>
 #include <thread>
 
 #include "session.hpp"
@@ -28,6 +29,11 @@ namespace trmf {
 inline int &tl_device() { static thread_local int d = -1; return d; }
 inline std::shared_ptr<Comm> &tl_comm() { static thread_local std::shared_ptr<Comm> c; return c; }
 
+// GroupRuntime: the worker threads, their ThreadGroup and their communicators for one device list.  Kept by the process between
+// sessions (GroupRuntime::acquire / release): the second c_trmf_train call of a grid_search neither starts threads nor sets up RCCL
+// again, and -- the communicators keeping their ids -- finds the first call's measure-once decisions in the process-level cache
+// (session.hpp: decision_cache) instead of spending up to 14 set-up iterations on measuring them again.  One session group uses a
+// runtime at a time; a concurrent group on the same device list gets a runtime of its own; a runtime whose group has failed is dropped.
 struct SessionGroup {
     struct Worker {
         std::thread th;
@@ -156,7 +162,42 @@ struct SessionGroup {
             if (impl[r]) { (void)impl[r]->sync(false); delete impl[r]; impl[r] = nullptr; }
             return 0;
         });
-        (void)on_all([&](int r) { comms[r].reset(); tl_comm().reset(); return 0; });
+    }
+    void drop_comms() { (void)on_all([&](int r) { comms[r].reset(); tl_comm().reset(); return 0; }); }
+
+    // ---- the runtimes the process keeps between sessions (see above) ----
+    static std::mutex &cache_mu() { static std::mutex m; return m; }
+    static std::map<std::string, std::vector<SessionGroup *>> &idle() { static auto *m = new std::map<std::string, std::vector<SessionGroup *>>(); return *m; }
+    static std::string key_of(const std::vector<int> &devices) {
+        std::string k;
+        for (int d : devices) k += std::to_string(d) + ",";
+        if (const char *e = getenv("TRMF_INPROC_COMM")) k += e;
+        return k;
+    }
+    std::string key;
+    // an idle runtime for this device list, or a new one with its communicator set up; nullptr (error text set) when that fails
+    static SessionGroup *acquire(const std::vector<int> &devices) {
+        const std::string k = key_of(devices);
+        {
+            std::lock_guard<std::mutex> lk(cache_mu());
+            auto &v = idle()[k];
+            if (!v.empty()) { SessionGroup *g = v.back(); v.pop_back(); return g; }
+        }
+        SessionGroup *g = new SessionGroup(devices);
+        g->key = k;
+        if (g->setup_comm()) { g->drop_comms(); delete g; return nullptr; }
+        return g;
+    }
+    // back to the cache when healthy (at most two idle runtimes per device list), torn down otherwise
+    static void release(SessionGroup *g) {
+        g->destroy_sessions();
+        if (!g->grp->failed.load()) {
+            std::lock_guard<std::mutex> lk(cache_mu());
+            auto &v = idle()[g->key];
+            if (v.size() < 2) { v.push_back(g); return; }
+        }
+        g->drop_comms();
+        delete g;
     }
 };
 

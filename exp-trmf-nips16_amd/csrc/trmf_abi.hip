@@ -131,7 +131,7 @@ struct SessionHandle {
         return group ? group->on_rank0([&](int) { return f(group->impl[0]); }) : f(single);
     }
     ~SessionHandle() {
-        if (group) { group->destroy_sessions(); delete group; }
+        if (group) SessionGroup::release(group);      // the sessions go; threads + communicators wait for the next call (session_group.hpp)
         else if (single) { (void)single->sync(false); delete single; }
     }
 };
@@ -151,8 +151,9 @@ static SessionHandle *make_session(const PyMatrix *Y, const uint32_t *lag_set, u
         if (!h->single) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
         return h.release();
     }
-    h->group = new SessionGroup(devs);
-    int rc = h->group->setup_comm();
+    h->group = SessionGroup::acquire(devs);
+    if (!h->group) { fprintf(stderr, "[ERR MSG]: %s\n", trmf_last_error()); return nullptr; }
+    int rc = 0;
     if (rc == 0)
         rc = h->group->on_all([&](int r) {          // every rank uploads the whole problem to its device and builds its session
             h->group->impl[r] = build_session(Y, lag_set, lag_size, W, H, LV, lambdaI, lambdaAR, lambdaLag, period_W, period_H, period_Lag, missing,

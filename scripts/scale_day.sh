@@ -1,6 +1,7 @@
 #!/bin/bash
 # Hardware-day checklist for DESIGN.md section 6: everything that has only ever run with processes / threads standing in
 # for GPUs, on a real multi-GPU node, in one go.   usage:  scripts/scale_day.sh [outdir] [gpu counts, default "1 2 4 8"]
+#   CFGS=c3 restricts the configurations.
 #   DRY=1 scripts/scale_day.sh out "1 2 4"      one-GPU box: N ranks as virtual ranks on device 0 (in-process mode, TRMF_DEVICES=0,0,...);
 #                                                the SPMD legs (torchrun, one process per GPU) are skipped
 # Per N and config (c3 = config 4's workload, c5): (1) SPMD launch -- one process per GPU under torch.distributed.run, RCCL over xGMI -- and
@@ -24,7 +25,7 @@ except Exception as exc:
     print('%-26s FAILED (%s)' % (sys.argv[2], exc))
 PY
 }
-for CFG in c3 c5; do
+for CFG in ${CFGS:-c3 c5}; do
   STEPS=20; WARM=5; [ $CFG = c5 ] && { STEPS=6; WARM=2; }
   for N in $NS; do
     if [ "${DRY:-0}" = 1 ]; then DEVS=$(python -c "print(','.join(['0'] * $N))"); else DEVS=$(python -c "print(','.join(str(i) for i in range($N)))"); fi

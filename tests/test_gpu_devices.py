@@ -117,6 +117,19 @@ def test_resident_session_api_under_TRMF_GPUS_style_lists(monkeypatch):
     assert _same(one, two) and J1 == J2
 
 
+def test_second_call_reuses_the_threads_communicators_and_decisions(monkeypatch):
+    """The worker threads and their communicators are kept by the process between sessions (session_group.hpp: GroupRuntime cache), so the
+    second call of a grid_search finds the first call's measure-once decisions in the process-level cache instead of measuring again."""
+    p, m0 = _problem('c4')
+    monkeypatch.setenv('TRMF_DEVICES', _devs('0,0'))
+    descs = []
+    for _ in range(2):
+        model = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), p['lag_set'])
+        with session.Session(p['Y'].astype(np.float32), model, missing=True, **synth.HYPER) as s:
+            s.run(2); descs.append(s.describe())
+    assert 'decided in' in descs[0] and '(cached)' in descs[1], descs
+
+
 def test_bad_device_lists_fail_loudly_and_leave_the_outputs_alone(monkeypatch):
     p, m0 = _problem('small')
     for bad in ('0,7', '0,x'):
