@@ -1006,7 +1006,7 @@ __global__ void gram_x_kernel(const uint32_t *__restrict__ ptr,
                                                      const real *__restrict__ Hf,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
-                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh);
+                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh, const uint32_t *__restrict__ order);
 template <int NT, bool RHS_PAD, bool PACKED>
 __global__ void gram_x_long_kernel(SplitRows sp, real *__restrict__ G, real *__restrict__ Bv, int k, size_t gs);
 template <int NT, bool RHS_PAD>
@@ -1054,7 +1054,8 @@ __device__ __forceinline__ void gram_x_body(const uint32_t *__restrict__ ptr,
                                                      const real *__restrict__ Hf,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
-                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh, const SplitRows &sp) {
+                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh, const SplitRows &sp,
+                                                     const uint32_t *__restrict__ order) {
     constexpr int KP = kTile * NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
@@ -1068,8 +1069,12 @@ __device__ __forceinline__ void gram_x_body(const uint32_t *__restrict__ ptr,
     } else {
     // one wavefront per timestamp; a workgroup is 4 wavefronts, or ONE where the rows' lengths differ widely (session_xphase.hpp:
     // a workgroup's wavefront slots are released together, so three short rows would wait for the fourth)
+    // `order` (skewed row lengths only): the rows longest first -- the hardware hands workgroups to SIMDs as slots free up, so with the long
+    // rows dispatched first the SIMDs' sums even out (longest-processing-time-first); in index order the busiest SIMD of a power-law pattern
+    // carries ~1.5x the mean (profiles/r06_split_rows.txt).  Each row's arithmetic is unchanged.
     row = row_begin + blockIdx.x * (blockDim.x >> 6) + (uint32_t)wave;
     if (row >= row_end) return;                         // wave-uniform; no block barrier below
+    if (order) row = (uint32_t)__builtin_amdgcn_readfirstlane((int)order[row]);
     const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
     const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
     if (p1 - p0 >= long_thresh) return;                 // a split row: gram_x_long_kernel writes its G_i / b_i
@@ -1132,12 +1137,12 @@ __global__ __launch_bounds__(256) void gram_x_kernel(const uint32_t *__restrict_
                                                      const real *__restrict__ Hf,
                                                      real *__restrict__ G, real *__restrict__ Bv,
                                                      uint32_t row_begin, uint32_t row_end, int k,
-                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh) {
-    gram_x_body<NT, RHS_PAD, PACKED, false>(ptr, idx, val, Hf, G, Bv, row_begin, row_end, k, zero_row, gs, long_thresh, SplitRows{});
+                                                     uint32_t zero_row, size_t gs, uint32_t long_thresh, const uint32_t *__restrict__ order) {
+    gram_x_body<NT, RHS_PAD, PACKED, false>(ptr, idx, val, Hf, G, Bv, row_begin, row_end, k, zero_row, gs, long_thresh, SplitRows{}, order);
 }
 template <int NT, bool RHS_PAD, bool PACKED>
 __global__ __launch_bounds__(256) void gram_x_long_kernel(SplitRows sp, real *__restrict__ G, real *__restrict__ Bv, int k, size_t gs) {
-    gram_x_body<NT, RHS_PAD, PACKED, true>(nullptr, nullptr, nullptr, nullptr, G, Bv, 0u, 0u, k, 0u, gs, 0u, sp);
+    gram_x_body<NT, RHS_PAD, PACKED, true>(nullptr, nullptr, nullptr, nullptr, G, Bv, 0u, 0u, k, 0u, gs, 0u, sp, nullptr);
 }
 #endif
 

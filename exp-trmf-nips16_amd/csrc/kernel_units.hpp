@@ -79,7 +79,7 @@ namespace trmf {
 #define TRMF_FSOLVE_ONE(X, NT, KMAX) X void fsolve_mfma_kernel<NT, KMAX> TRMF_FSOLVE_SIG;
 #define TRMF_FSOLVE_LONG_ONE(X, NT, KMAX) X void fsolve_mfma_long_kernel<NT, KMAX> TRMF_FSOLVE_LONG_SIG;
 #endif
-#define TRMF_GRAMX_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, real *, uint32_t, uint32_t, int, uint32_t, size_t, uint32_t)
+#define TRMF_GRAMX_SIG (const uint32_t *, const uint32_t *, const real *, const real *, real *, real *, uint32_t, uint32_t, int, uint32_t, size_t, uint32_t, const uint32_t *)
 // the split path of long rows (gram_kernels.hpp "split rows"): partial Grams per item, then the row kernels' second halves
 #define TRMF_GRAMX_LONG_SIG (SplitRows, real *, real *, int, size_t)
 #define TRMF_GRAM_PART_SIG (const uint32_t *, const real *, const real *, const uint32_t *, uint32_t, uint32_t, real *, uint32_t, uint32_t)

@@ -381,7 +381,7 @@ struct TrmfSessionImpl : SessionXPhase {
         TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         const int waves = std::max(1, prop.multiProcessorCount) * 12;        // three wavefronts per SIMD: what the Gram kernels are built for
         if (build_long_rows(longF, host_col_ptr, (size_t)n, sizeof(real) == 4 ? 512u : 2048u, waves) ||
-            build_long_rows(longX, host_row_ptr, (size_t)T, 2048u, waves)) return kFail;
+            build_long_rows(longX, host_row_ptr, (size_t)T, 2048u, waves, true)) return kFail;
         const uint32_t items = std::max(longF.nitems, longX.nitems);
         if (!items) return 0;
         switch (NT) {

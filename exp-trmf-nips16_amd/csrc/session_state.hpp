@@ -339,11 +339,12 @@ struct SessionState {
         uint32_t thresh = 0xffffffffu, chunk = 1024;
         std::vector<uint32_t> rows, first;    // host copies: ids of the long rows (ascending), first item of each (+ one past the last)
         DevBuf<uint32_t> d_rows, d_first, d_items;   // d_items: (begin, end) entry positions per item
+        DevBuf<uint32_t> d_order;             // skewed: every row of the orientation, longest first (gram_x_kernel's dispatch order)
         uint32_t nitems = 0;
         uint64_t nnz_long = 0;
         bool skewed = false;                  // among the rows that stay on the row kernels the longest is >= 2x the mean (and the mean >= 64 entries)
         bool any() const { return !rows.empty(); }
-        void clear() { thresh = 0xffffffffu; skewed = false; rows.clear(); first.clear(); nitems = 0; nnz_long = 0; d_rows.release(); d_first.release(); d_items.release(); }
+        void clear() { thresh = 0xffffffffu; skewed = false; rows.clear(); first.clear(); nitems = 0; nnz_long = 0; d_rows.release(); d_first.release(); d_items.release(); d_order.release(); }
         // positions [lo, hi) of the list whose rows lie in [rb, re)
         void range(uint32_t rb, uint32_t re, uint32_t &lo, uint32_t &hi) const {
             lo = (uint32_t)(std::lower_bound(rows.begin(), rows.end(), rb) - rows.begin());
@@ -353,7 +354,7 @@ struct SessionState {
     DevBuf<real> part_slab;                   // partial Grams of the items of ONE orientation at a time (F-solve, then X-side Gram)
     uint32_t part_stride = 0;                 // reals per item: upper tiles in accumulator layout + the lane groups' rhs partials
     static constexpr uint32_t kSplitMaxItemsPerRow = 256;
-    int build_long_rows(LongRows &L, const std::vector<uint64_t> &ptr, size_t nrows, uint32_t lo_entries, int resident_waves) {
+    int build_long_rows(LongRows &L, const std::vector<uint64_t> &ptr, size_t nrows, uint32_t lo_entries, int resident_waves, bool want_order = false) {
         L.rows.clear(); L.first.clear(); L.nitems = 0; L.nnz_long = 0;
         const uint64_t total = nrows ? ptr[nrows] - ptr[0] : 0;
         uint64_t th = (total / (8ull * (uint64_t)std::max(resident_waves, 1)) + 15) / 16 * 16;
@@ -376,6 +377,15 @@ struct SessionState {
         }
         L.first.push_back(L.nitems);
         L.skewed = short_rows > 0 && short_sum >= 64 * short_rows && short_max * short_rows >= 2 * short_sum;
+        if (L.skewed && want_order) {
+            std::vector<uint32_t> ord(nrows);
+            for (size_t r = 0; r < nrows; r++) ord[r] = (uint32_t)r;
+            std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {
+                const uint64_t la = ptr[a + 1] - ptr[a], lb = ptr[b + 1] - ptr[b];
+                return (la >= L.thresh ? 0 : la) > (lb >= L.thresh ? 0 : lb);       // split rows return at once: with the empty ones, last
+            });
+            if (L.d_order.upload(ord.data(), ord.size())) return kFail;
+        } else L.d_order.release();
         if (L.rows.empty()) { L.d_rows.release(); L.d_first.release(); L.d_items.release(); return 0; }
         return L.d_rows.upload(L.rows.data(), L.rows.size()) || L.d_first.upload(L.first.data(), L.first.size()) || L.d_items.upload(items.data(), items.size()) ? kFail : 0;
     }

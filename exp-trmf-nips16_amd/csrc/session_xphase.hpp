@@ -87,6 +87,8 @@ struct SessionXPhase : SessionFPhase {
         uint32_t lo = 0, hi = 0;
         if (longX.any()) longX.range(rb, re, lo, hi);     // split timestamps: partial Grams per item, then their sums -> G_i / b_i
         const dim3 lgrid((hi - lo + 3) / 4);
+        // longest rows first (LongRows::d_order) when the launch covers every timestamp; a rank's block runs in index order
+        const uint32_t *xorder = (longX.skewed && longX.d_order.p && rb == 0 && re == (uint32_t)T) ? longX.d_order.p : nullptr;
 #define TRMF_LAUNCH_GRAM_X(PAD, PACKED)                                                                                      \
     do {                                                                                                                     \
         if (hi > lo) {                                                                                                       \
@@ -94,7 +96,7 @@ struct SessionXPhase : SessionFPhase {
             hipLaunchKernelGGL((gram_x_long_kernel<NT_, PAD, PACKED>), lgrid, lblock, 0, stream, split_view(longX, lo, hi), G.p, Bv.p, k, xp.gstride); \
         }                                                                                                                    \
         hipLaunchKernelGGL((gram_x_kernel<NT_, PAD, PACKED>), grid, block, 0, stream, Yr_ptr.p, Yr_idx.p, Yr_val.p, H.p, G.p, Bv.p, \
-                           rb, re, k, (uint32_t)n, xp.gstride, longX.thresh);                                                \
+                           rb, re, k, (uint32_t)n, xp.gstride, longX.thresh, xorder);                                        \
     } while (0)
         if (rhs_pad_ok<NT_>(k)) {     // rhs accumulated by the MFMAs in the panel's pad columns
             if (gpacked) TRMF_LAUNCH_GRAM_X(true, true); else TRMF_LAUNCH_GRAM_X(true, false);

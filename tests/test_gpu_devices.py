@@ -122,6 +122,7 @@ def test_second_call_reuses_the_threads_communicators_and_decisions(monkeypatch)
     second call of a grid_search finds the first call's measure-once decisions in the process-level cache instead of measuring again."""
     p, m0 = _problem('c4')
     monkeypatch.setenv('TRMF_DEVICES', _devs('0,0'))
+    monkeypatch.setenv('TRMF_PERSIST_TIMEOUT_MS', '2001')      # part of the decision cache's key (every TRMF_* variable is): a key no earlier test of this process has used
     descs = []
     for _ in range(2):
         model = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), p['lag_set'])
