@@ -99,7 +99,7 @@ def _single_process(p, m0, dtype, iters):
 @pytest.mark.parametrize('world,shape,mode', [(2, 'small', 'timeshard'), (2, 'odd', 'timeshard'), (2, 'c4', 'timeshard'),
                                               (4, 'c4', 'timeshard'), (8, 'c4', 'timeshard'), (3, 'c4', 'measure'),
                                               (4, 'c4', 'replicate'), (3, 'c4', 'overlap'), (2, 'odd', 'overlap'), (2, 'small', 'p2p'), (2, 'c4', 'p2p'), (4, 'c4', 'p2p'),
-                                              (8, 'c4', 'p2p'), (2, 'small', 'persist'), (3, 'odd', 'persist'), (2, 'c4', 'persist'), (4, 'c4', 'persist')])
+                                              (8, 'c4', 'p2p'), (3, 'c4', 'split'), (2, 'small', 'persist'), (3, 'odd', 'persist'), (2, 'c4', 'persist'), (4, 'c4', 'persist')])
 def test_time_sharded_cg_matches_single_process(world, shape, mode):
     """The CG sharded over TIME: every rank runs the tiles of its own block of timestamps, the tile
     records (three scalars per CG step) and midx halo rows per neighbour are exchanged after every launch.  Same
@@ -119,17 +119,29 @@ def test_time_sharded_cg_matches_single_process(world, shape, mode):
     env = {} if mode == 'measure' else {'TRMF_CG': mode}
     if mode == 'persist':       # processes sharing ONE device may be time-sliced against each other: slow progress must not read as a failure here
         env['TRMF_PERSIST_TIMEOUT_MS'] = '120000'
+    if mode == 'split':         # the split path of long rows (forced geometry): every rank covers the positions of the long-row list inside its block
+        env = {'TRMF_LONG_ROW': '40', 'TRMF_LONG_CHUNK': '32', 'TRMF_CG': 'timeshard'}
     if mode == 'overlap':       # the F-solve in two launches, the first halves of H gathered on a side stream under the second
         env = {'TRMF_FOVERLAP': '4' if world == 3 else '2', 'TRMF_FSHARD': 'shard', 'TRMF_CG': 'timeshard'}     # chunks
     out = dict(_spawn(dist_worker.gpu_host_staged, world, iters, shape, env))
     p, m0 = dist_worker._problem(shape)
     for dtype in (np.float32, np.float64):
         name = np.dtype(dtype).name
-        model, cg1 = _single_process(p, m0, dtype, iters)
+        keep = {k: os.environ.get(k) for k in ('TRMF_LONG_ROW', 'TRMF_LONG_CHUNK')}
+        if mode == 'split':     # the one-rank reference splits the same rows into the same items
+            os.environ.update({k: env[k] for k in keep})
+        try:
+            model, cg1 = _single_process(p, m0, dtype, iters)
+        finally:
+            for k, v in keep.items():
+                if v is None: os.environ.pop(k, None)
+                else: os.environ[k] = v
         for r in range(world):
             W, H, Th, cg, second_session_same = out[r][name][:5]
             assert np.array_equal(W, model.W) and np.array_equal(H, model.H) and np.array_equal(Th, model.lag_val), (r, name)
             assert cg == cg1 and second_session_same
+            if mode == 'split':
+                assert 'split rows' in out[r][name][6], out[r][name][6]
             if mode == 'persist':
                 assert 'one persistent kernel per rank' in out[r][name][6], out[r][name][6]
 
