@@ -10,6 +10,6 @@ else RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.ubsan_standalo
 cd $R
 TRMF_CORELIB_DIR=$R/exp-trmf-nips16_amd/build/asan LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0 \
   UBSAN_OPTIONS=print_stacktrace=1 timeout 2400 python -m pytest tests/test_abi.py tests/test_gpu_parity.py tests/test_python_frontend.py tests/test_gpu_oneshot.py tests/test_gpu_devices.py tests/test_gpu_split.py \
-  tests/test_dist.py -m gpu -x -q -k "not full_size and not c3full and not config4 and not c5s" > $OUT 2>&1
+  tests/test_dist.py -m gpu -x -q -k "not full_size and not c3full and not config4 and not c5s and not forced_split_every" > $OUT 2>&1
 echo "asan pytest exit $?" >> $OUT
 grep -c "ERROR: AddressSanitizer\|runtime error:" $OUT
