@@ -100,7 +100,7 @@ def evidence(line):
 def fp32_noise_yardstick(Y, lag_set, W0, H0, Th0, hyper, iters, periods=(1, 1, 2), threads=None, with_ref=True):
     import oracle_py as O
     ncpu = os.cpu_count() or 8
-    threads = threads or ncpu
+    threads = threads or (ncpu if Y.nnz > 2000000 else min(8, ncpu))      # small problems: OpenMP region entry on 256 threads dominates
     Y64 = Y.astype(np.float64)
     W64, H64 = W0.astype(np.float64), H0.astype(np.float64)
     T64 = np.asfortranarray(Th0.astype(np.float64))
@@ -117,7 +117,7 @@ def fp32_noise_yardstick(Y, lag_set, W0, H0, Th0, hyper, iters, periods=(1, 1, 2
     O.train_port(Y32, lag_set, W, H, Th, hyper, max_iter=iters, periods=periods, threads=threads)
     dist('restatement fp32', W, H, Th)
     if with_ref and O.ref(np.float32) is not None:
-        for t in sorted({min(64, ncpu), min(8, ncpu)}):
+        for t in sorted({min(64, ncpu) if Y.nnz > 2000000 else min(16, ncpu), min(8, ncpu)}):
             W, H, Th = W0.astype(np.float32), H0.astype(np.float32), np.asfortranarray(Th0.astype(np.float32))
             O.train_ref(Y32, lag_set, W, H, Th, hyper, max_iter=iters, periods=periods, threads=t)
             dist('reference fp32 build, %d threads' % t, W, H, Th)

@@ -33,7 +33,9 @@ def run_product(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
 
 def run_oracle(Y, lag_set, W0, H0, Th0, hyper, max_iter, periods=(1, 1, 2)):
     W, H, Th = W0.copy(), H0.copy(), np.asfortranarray(Th0.copy())
-    log = O.train_port(Y, lag_set, W, H, Th, hyper, max_iter=max_iter, periods=periods, threads=NCPU)
+    # (a small problem on all 256 hardware threads of the GPU box spends its time entering OpenMP regions: 65 s per forced-split case)
+    threads = NCPU if Y.nnz > 2000000 else min(8, NCPU)
+    log = O.train_port(Y, lag_set, W, H, Th, hyper, max_iter=max_iter, periods=periods, threads=threads)
     return W, H, Th, log
 
 
@@ -77,7 +79,7 @@ def test_forced_split_every_row_vs_oracle(dtype, k, nlag, path, monkeypatch):
     if not direct:
         # fp32 only: the truncated CG's noise floor, measured on the reference side on the same inputs (helpers.fp32_noise_yardstick)
         assert dtype == np.float32, (abs(Jp - Jo) / Jo, relfro(m.H, H), relfro(m.W, W))
-        ys = fp32_noise_yardstick(Y, lags, m0.W, m0.H, m0.lag_val, synth.HYPER, 3)
+        ys = fp32_noise_yardstick(Y, lags, m0.W, m0.H, m0.lag_val, synth.HYPER, 3, threads=min(8, NCPU))
         assert_within_fp32_noise(m, ys, lags, synth.HYPER, what='forced split k=%d |L|=%d %s' % (k, nlag, path))
     d = describe_of(Y, make_model(m0.W, m0.H, m0.lag_val, lags), synth.HYPER)
     assert 'split rows' in d and 'F 700 rows' in d and 'X 520 rows' in d, d
