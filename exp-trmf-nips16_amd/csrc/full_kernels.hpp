@@ -23,22 +23,29 @@ __global__ void spmm_rows_kernel(const uint32_t *__restrict__ ptr,
                                                         const real *__restrict__ val,
                                                         const real *__restrict__ X,
                                                         real *__restrict__ out, uint32_t row_begin,
-                                                        uint32_t row_end, uint32_t zero_row);
-#else
+                                                        uint32_t row_end, uint32_t zero_row, uint32_t long_thresh);
+// a split row's item (gram_kernels.hpp "split rows"): the same sum over entries [items[2 i], items[2 i + 1]) -> part[i][0 .. KP)
 template <int NT>
-__global__ __launch_bounds__(256) void spmm_rows_kernel(const uint32_t *__restrict__ ptr,
+__global__ void spmm_part_kernel(const uint32_t *__restrict__ idx, const real *__restrict__ val, const real *__restrict__ X,
+                                 const uint32_t *__restrict__ items, uint32_t item_begin, uint32_t item_end, real *__restrict__ part,
+                                 uint32_t zero_row);
+#else
+// ITEM: one wavefront per item of a split row instead of per row
+template <int NT, bool ITEM>
+__device__ __forceinline__ void spmm_body(const uint32_t *__restrict__ ptr,
                                                         const uint32_t *__restrict__ idx,
                                                         const real *__restrict__ val,
                                                         const real *__restrict__ X,
                                                         real *__restrict__ out, uint32_t row_begin,
-                                                        uint32_t row_end, uint32_t zero_row) {
+                                                        uint32_t row_end, uint32_t zero_row, uint32_t long_thresh) {
     constexpr int KP = kTile * NT;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = row_begin + blockIdx.x * 4u + (uint32_t)wave;
     if (row >= row_end) return;
-    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row]);
-    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[row + 1]);
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[ITEM ? 2 * row : row]);
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ptr[ITEM ? 2 * row + 1 : row + 1]);
+    if (!ITEM && p1 - p0 >= long_thresh) return;        // a split row: spmm_part_kernel + spmm_reduce_kernel write it
     GramState<NT> st;
     st.clear();
     real nowq[NT];
@@ -54,6 +61,36 @@ __global__ __launch_bounds__(256) void spmm_rows_kernel(const uint32_t *__restri
         v += __shfl_xor(v, 32, kWave);
         if (g == 0) out[(size_t)row * KP + kTile * q + c] = v;
     }
+}
+template <int NT>
+__global__ __launch_bounds__(256) void spmm_rows_kernel(const uint32_t *__restrict__ ptr,
+                                                        const uint32_t *__restrict__ idx,
+                                                        const real *__restrict__ val,
+                                                        const real *__restrict__ X,
+                                                        real *__restrict__ out, uint32_t row_begin,
+                                                        uint32_t row_end, uint32_t zero_row, uint32_t long_thresh) {
+    spmm_body<NT, false>(ptr, idx, val, X, out, row_begin, row_end, zero_row, long_thresh);
+}
+template <int NT>
+__global__ __launch_bounds__(256) void spmm_part_kernel(const uint32_t *__restrict__ idx, const real *__restrict__ val,
+                                                        const real *__restrict__ X, const uint32_t *__restrict__ items,
+                                                        uint32_t item_begin, uint32_t item_end, real *__restrict__ part, uint32_t zero_row) {
+    spmm_body<NT, true>(items, idx, val, X, part, item_begin, item_end, zero_row, 0u);
+}
+#endif
+
+#if !defined(TRMF_UNIT)      // compiled by the main translation unit only (kernel_units.hpp)
+// out[row of long-row position li][:] = the row's item partials summed in item order (one thread per column)
+__global__ __launch_bounds__(256) void spmm_reduce_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ first,
+                                                          const real *__restrict__ part, real *__restrict__ out, uint32_t begin,
+                                                          uint32_t end, int KP) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t li = begin + (uint32_t)(e / (size_t)KP);
+    if (li >= end) return;
+    const int col = (int)(e % (size_t)KP);
+    real acc = 0;
+    for (uint32_t it = first[li]; it < first[li + 1]; it++) acc += part[(size_t)it * KP + col];
+    out[(size_t)rows[li] * KP + col] = acc;
 }
 #endif
 

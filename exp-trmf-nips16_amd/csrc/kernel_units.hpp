@@ -110,7 +110,8 @@ namespace trmf {
 // non-template kernels of cg_kernels.hpp / generic_kernels.hpp LLVM's CodeGenPrepare spent 175 s of the main unit's 180 s.
 #define TRMF_APPLY_SHARED_SIG (XParams, const XState *, int, const real *, const real *, const real *, const real *, const real *, int, real *, int, double *, int, int, int)
 #define TRMF_FULL_NT(X, NT)                                                                                                              \
-    X void spmm_rows_kernel<NT>(const uint32_t *, const uint32_t *, const real *, const real *, real *, uint32_t, uint32_t, uint32_t);  \
+    X void spmm_rows_kernel<NT>(const uint32_t *, const uint32_t *, const real *, const real *, real *, uint32_t, uint32_t, uint32_t, uint32_t);  \
+    X void spmm_part_kernel<NT>(const uint32_t *, const real *, const real *, const uint32_t *, uint32_t, uint32_t, real *, uint32_t);  \
     X void dense_tn_mfma_kernel<NT>(const real *, int, int, const real *, double *);                                                    \
     X void small_gram_mfma_kernel<NT>(const real *, int, int, double *);                                                                \
     X void chol_wave_kernel<NT>(const real *, real *, int);                                                                             \

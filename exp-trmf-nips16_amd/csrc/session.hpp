@@ -374,16 +374,20 @@ struct TrmfSessionImpl : SessionXPhase {
     int setup_split_rows() {
         longF.clear(); longX.clear();
         part_slab.release(); part_stride = 0;
-        if (dense || full || generic) return 0;
+        if (dense || generic) return 0;
         hipDeviceProp_t prop;
         int dev = 0;
         TRMF_HIP_CHECK(hipGetDevice(&dev));
         TRMF_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         const int waves = std::max(1, prop.multiProcessorCount) * 12;        // three wavefronts per SIMD: what the Gram kernels are built for
-        if (build_long_rows(longF, host_col_ptr, (size_t)n, sizeof(real) == 4 ? 512u : 2048u, waves) ||
+        if (build_long_rows(longF, host_col_ptr, (size_t)n, (sizeof(real) == 4 && !full) ? 512u : 2048u, waves) ||
             build_long_rows(longX, host_row_ptr, (size_t)T, 2048u, waves, true)) return kFail;
         const uint32_t items = std::max(longF.nitems, longX.nitems);
         if (!items) return 0;
+        if (full) {                      // sparse Y with missing == 0: the items' partial rows of Y^T W / Y H (spmm_part_kernel), KP values each
+            part_stride = (uint32_t)KP;
+            return part_slab.alloc((size_t)items * part_stride, false);
+        }
         switch (NT) {
             case 1: part_stride = split_part_reals<1>(true); break;
             case 2: part_stride = split_part_reals<2>(true); break;

@@ -176,11 +176,22 @@ struct SessionFPhase : SessionTransport {
     }
 
     // ---- full-observation path (missing == 0): trmf.cpp:299-351 and 155-215 -----------------------------
-    template <int NT_> void launch_spmm(const uint32_t *ptr, const uint32_t *idx, const real *val, const real *X,
+    // sparse Y times a factor (full-observation path with a sparse Y): rows of the orientation `L` describes; its split rows go through
+    // spmm_part_kernel (one wavefront per item) + spmm_reduce_kernel (item order), the others through the row kernel
+    template <int NT_> void launch_spmm(const LongRows &L, const uint32_t *ptr, const uint32_t *idx, const real *val, const real *X,
                                         real *out, uint32_t rb, uint32_t re, uint32_t zero_row) {
-        if (re > rb)
-            hipLaunchKernelGGL((spmm_rows_kernel<NT_>), dim3((re - rb + 3) / 4), dim3(256), 0, stream, ptr, idx, val, X,
-                               out, rb, re, zero_row);
+        if (re <= rb) return;
+        if (L.any()) {
+            uint32_t lo, hi;
+            L.range(rb, re, lo, hi);
+            const uint32_t i0 = L.first[lo], i1 = L.first[hi];
+            if (i1 > i0) {
+                hipLaunchKernelGGL((spmm_part_kernel<NT_>), dim3((i1 - i0 + 3) / 4), dim3(256), 0, stream, idx, val, X, L.d_items.p, i0, i1, part_slab.p, zero_row);
+                hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)(((size_t)(hi - lo) * KP + 255) / 256)), dim3(256), 0, stream, L.d_rows.p, L.d_first.p,
+                                   part_slab.p, out, lo, hi, KP);
+            }
+        }
+        hipLaunchKernelGGL((spmm_rows_kernel<NT_>), dim3((re - rb + 3) / 4), dim3(256), 0, stream, ptr, idx, val, X, out, rb, re, zero_row, L.thresh);
     }
     template <int NT_> void launch_dense_tn(const real *A, int K, int M, const real *B, real *out) {
         // contraction chunks: enough workgroups (64 output rows each) to fill the chip even when there are only a few
@@ -215,10 +226,10 @@ struct SessionFPhase : SessionTransport {
             const real *val = transposed ? Yc_val.p : Yr_val.p;
             const uint32_t zr = (uint32_t)(transposed ? T : n);
             switch (NT) {
-                case 1: launch_spmm<1>(ptr, idx, val, X, out, rb, re, zr); break;
-                case 2: launch_spmm<2>(ptr, idx, val, X, out, rb, re, zr); break;
-                case 3: launch_spmm<3>(ptr, idx, val, X, out, rb, re, zr); break;
-                default: launch_spmm<4>(ptr, idx, val, X, out, rb, re, zr); break;
+                case 1: launch_spmm<1>(transposed ? longF : longX, ptr, idx, val, X, out, rb, re, zr); break;
+                case 2: launch_spmm<2>(transposed ? longF : longX, ptr, idx, val, X, out, rb, re, zr); break;
+                case 3: launch_spmm<3>(transposed ? longF : longX, ptr, idx, val, X, out, rb, re, zr); break;
+                default: launch_spmm<4>(transposed ? longF : longX, ptr, idx, val, X, out, rb, re, zr); break;
             }
         } else {
             const real *A = transposed ? Yd_tn.p : Yd_nt.p;     // K x M row-major with K the contracted dim

@@ -172,3 +172,34 @@ def test_long_row_workloads_full_size_vs_oracle(cfgname):
     evidence('%s full size: one F-solve, %d split item rows: relmax(H rows) %.2e; all rows %.2e' % (
         cfgname, len(long_items), relmax(mf.H[long_items], Hf[long_items]), relmax(mf.H, Hf)))
     assert relmax(mf.H[long_items], Hf[long_items]) < 2e-4 and relmax(mf.H, Hf) < 2e-4
+
+
+@pytest.mark.parametrize('dtype,k', [(np.float32, 40), (np.float64, 24), (np.float32, 16)])
+def test_full_observation_path_with_a_sparse_Y_splits_long_rows_too(dtype, k, monkeypatch):
+    """missing = 0 with a SPARSE Y (zeros are observations; trmf.cpp:299-351, 155-215 through gmat_x_dmat): the products Y^T W and Y H are
+    one wavefront per row in spmm_rows_kernel; rows above the threshold go through spmm_part_kernel + spmm_reduce_kernel (item order).
+    Forced geometry (every row split) and, second, the default rule on a pattern with complete series / census timestamps."""
+    p = synth.sparse_problem(n=700, T=520, k=k, nlag=4, density=0.2, dtype=dtype, seed=17)
+    q = synth.powerlaw_problem(3000, 2600, k, [1, 2, 3, 4], nnz0=120000, alpha_items=0.3, alpha_time=0.2, full_items=3, full_times=2, dtype=dtype, seed=5)
+    tol = TOL[np.dtype(dtype).name]
+    for prob, forced in ((p, True), (q, False)):
+        Y, lags = prob['Y'], prob['lag_set']
+        m0 = synth.initial_model(Y, lags, k, seed=17)
+        if forced:
+            monkeypatch.setenv('TRMF_LONG_ROW', '24'); monkeypatch.setenv('TRMF_LONG_CHUNK', '32')
+        else:
+            monkeypatch.delenv('TRMF_LONG_ROW', raising=False); monkeypatch.delenv('TRMF_LONG_CHUNK', raising=False)
+        model = make_model(m0.W, m0.H, m0.lag_val, lags)
+        with session.Session(Y, model, missing=False, **synth.HYPER) as s:
+            d = s.describe()
+            s.run(3); s.download()
+        assert 'split rows' in d, d
+        W, H, Th = m0.W.copy(), m0.H.copy(), np.asfortranarray(m0.lag_val.copy())
+        O.train_port(Y, lags, W, H, Th, synth.HYPER, max_iter=3, missing=False, threads=min(8, NCPU))
+        assert relfro(model.H, H) < tol['factor'] and relfro(model.W, W) < tol['factor'] and relfro(model.lag_val, Th) < tol['factor'] * 10, \
+            (forced, relfro(model.H, H), relfro(model.W, W))
+        if not forced:      # and the same bits as the row kernels' single chains up to rounding: switch the path off
+            monkeypatch.setenv('TRMF_LONG_ROW', '0')
+            base = make_model(m0.W, m0.H, m0.lag_val, lags)
+            trmf.train(Y, base, max_iter=3, missing=False, **synth.HYPER)
+            assert relfro(model.H, base.H) < tol['factor'] and not np.array_equal(model.H, base.H)
