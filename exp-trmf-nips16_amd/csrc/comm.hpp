@@ -58,6 +58,9 @@ struct Comm {
     virtual int device_of(int /*rank*/) const { return -1; }
     // all ranks of an in-process group meet here (no-op elsewhere): frees of memory that peers store into are ordered behind it
     virtual int barrier() { return 0; }
+    // this rank is about to give up (in-process groups: breaks the group's barrier so that no peer waits for it -- or mistakes a barrier
+    // this rank passes on its way out for the one of the collective they are in)
+    virtual void abort() {}
 };
 
 // ---- equal-slot staging shared by the communicators -----------------------------------------------
@@ -238,6 +241,7 @@ struct ThreadComm : Comm {
         if (grp->barrier()) { set_error("another rank of the in-process group failed"); return kFail; }
         return 0;
     }
+    void abort() override { grp->fail(); }
     int pull(void *dbuf, const uint64_t *begin, const uint64_t *end, hipStream_t stream) {
         auto bail = [&](const char *what) { grp->fail(); set_error(what); return kFail; };
         {
@@ -320,6 +324,7 @@ struct RcclComm : Comm {
         if (grp && grp->barrier()) { set_error("another rank of the in-process group failed"); return kFail; }
         return 0;
     }
+    void abort() override { if (grp) grp->fail(); }
     ~RcclComm() override {
         if (!comm) return;
         int prev = -1;

@@ -113,7 +113,12 @@ static TrmfSessionImpl *build_session(const PyMatrix *Y, const uint32_t *lag_set
     s->lambdaI = lambdaI; s->lambdaAR = lambdaAR; s->lambdaLag = lambdaLag;
     s->period_W = period_W; s->period_H = period_H; s->period_Lag = period_Lag; s->verbose = verbose;
     s->full = (missing == 0);
-    if (s->create(Y, lag_set, lag_size, W, H, LV)) return nullptr;
+    if (s->create(Y, lag_set, lag_size, W, H, LV)) {
+        const std::string why = SessionGroup::trmf_last_error_text();
+        active_comm()->abort();          // before the half-built session is torn down (its teardown passes the group's barrier)
+        set_error(why);
+        return nullptr;
+    }
     return s.release();
 }
 
