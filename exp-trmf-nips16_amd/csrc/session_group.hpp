@@ -188,6 +188,15 @@ struct SessionGroup {
         if (g->setup_comm()) { g->drop_comms(); delete g; return nullptr; }
         return g;
     }
+    // trmf_release_cached(): idle runtimes (threads, communicators) go too
+    static void drop_idle() {
+        std::vector<SessionGroup *> all;
+        {
+            std::lock_guard<std::mutex> lk(cache_mu());
+            for (auto &kv : idle()) { all.insert(all.end(), kv.second.begin(), kv.second.end()); kv.second.clear(); }
+        }
+        for (SessionGroup *g : all) { g->drop_comms(); delete g; }
+    }
     // back to the cache when healthy (at most two idle runtimes per device list), torn down otherwise
     static void release(SessionGroup *g) {
         g->destroy_sessions();

@@ -287,6 +287,7 @@ int32_t trmf_last_train_profile(TrmfTrainProfile *out) {
     return 0;
 }
 int32_t trmf_release_cached(void) {
+    SessionGroup::drop_idle();           // worker threads + communicators of the TRMF_DEVICES mode kept between calls
     DeviceGuard guard;
     if (!guard.ok) return kFail;
     DevicePool::current().trim();

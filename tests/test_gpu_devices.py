@@ -129,6 +129,12 @@ def test_second_call_reuses_the_threads_communicators_and_decisions(monkeypatch)
         with session.Session(p['Y'].astype(np.float32), model, missing=True, **synth.HYPER) as s:
             s.run(2); descs.append(s.describe())
     assert 'decided in' in descs[0] and '(cached)' in descs[1], descs
+    # trmf_release_cached() also retires the idle worker threads and their communicators: the next session measures again
+    assert session.lib_for(np.float32).trmf_release_cached() == 0
+    model = make_model(m0.W.astype(np.float32), m0.H.astype(np.float32), np.asfortranarray(m0.lag_val.astype(np.float32)), p['lag_set'])
+    with session.Session(p['Y'].astype(np.float32), model, missing=True, **synth.HYPER) as s:
+        s.run(1); d3 = s.describe()
+    assert '(cached)' not in d3, d3
 
 
 def test_bad_device_lists_fail_loudly_and_leave_the_outputs_alone(monkeypatch):
