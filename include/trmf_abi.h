@@ -132,7 +132,7 @@ typedef struct {
 /* 0 and *out filled when a c_trmf_train call has completed in this process (and library), -1 otherwise. */
 TRMF_API int32_t trmf_last_train_profile(TrmfTrainProfile *out);
 /* Give back what the library keeps between calls on the selected device: pooled device memory (when no session is alive),
- * idle streams, the pinned upload ring (24 MB) and the pinned download staging.  TRMF_POOL_MAX_MB (default 8192, 0 = keep
+ * idle streams, the pinned upload ring (24 MB) and the pinned download staging, the idle worker threads / communicators of the TRMF_DEVICES mode.  TRMF_POOL_MAX_MB (default 8192, 0 = keep
  * nothing) bounds the pool.  Returns 0, or -1 when the selected device cannot be made current (trmf_last_error() says why). */
 TRMF_API int32_t trmf_release_cached(void);
 
