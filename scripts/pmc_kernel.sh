@@ -10,7 +10,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
          "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES" \
          "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES TCP_TOTAL_CACHE_ACCESSES TCP_TCC_READ_REQ" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT TCC_MISS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$RE" --output-format csv -d $R/gpurun_out/$OUT/p$i -o pmc -- python $R/bench.py --config ${CFG:-c3} --no-cpu-baseline --steps 4 --warmup 1 > $R/gpurun_out/$OUT/p$i.log 2>&1 || echo "pass $i failed"
+  rocprofv3 --kernel-trace --pmc $C --kernel-include-regex "$RE" --output-format csv -d $R/gpurun_out/$OUT/p$i -o pmc -- python $R/bench.py --config ${CFG:-c3} --no-cpu-baseline --no-one-shot --repeat 1 --steps 4 --warmup 1 > $R/gpurun_out/$OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python - <<PY
 import csv, glob, collections
